@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Gkeys/s on uniform-random u32 keys (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one complete radix sort of one batch of synthetic keys that is already resident in HBM:
+  N = 1 : BASELINE config #2, key-only RadixSort32, 64Mi uniform-random u32 keys, in place
+          (Pprims::radixSort path: adlhip_radix_sort_u32).
+  N > 1 : every rank holds 64Mi keys (weak scaling); a step = MSB-bucket partition -> RCCL all-to-all
+          -> local sort (oclradixsort_amd/dist.py).
+Every step sorts its OWN pre-generated random buffer (K + W buffers of 256 MiB are generated on the
+device before the timed region), so no step sees pre-sorted data and no restore copy is timed.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline     : dominant kernel (the per-digit sort+scatter pass), ALGORITHMIC bytes per launch =
+                 2*n*E (read n*E + write n*E) / its average launch duration,
+                 measured here with hipEvents on the library's own stream in a second, profiled loop
+                 over the same inputs (toggleProfiling brackets every launch with an event pair).
+  cpu_baseline : the reference's single-threaded CPU sort (oracle/_ref, else the oracle port) timed on
+                 this host on the same 64Mi-key workload (N = 1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_KEYS = 1 << 26            # 64Mi keys per GPU
+ELEM_BYTES = 4
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+ALGO_BYTES_PER_KEY_SORT = 96.0   # 8 four-bit passes x 3 x 4 B (the reference's pass count)
+
+
+def cpu_baseline(n):
+    """Reference CPU path (single thread) on a bounded sample: the same n-key workload, repeated until
+    about 10 s of CPU work is reached (at least 2, at most 4 runs)."""
+    import oracle
+    keys = oracle.keys_u32(n, seed=123)
+    kind = "reference" if oracle.have_ref() else "port"
+    fn = oracle.ref_sort_u32 if kind == "reference" else oracle.sort_u32
+    times = []
+    t_total = 0.0
+    while len(times) < 2 or (t_total < 10.0 and len(times) < 4):
+        work = keys.copy()
+        t0 = time.perf_counter()
+        if kind == "reference":
+            oracle.ref().ref_radix_sort_u32(work.ctypes.data_as(oracle._u32p), work.size)
+        else:
+            oracle.lib().oracle_radix_sort_u32(work.ctypes.data_as(oracle._u32p), work.size)
+        dt = time.perf_counter() - t0
+        times.append(dt)
+        t_total += dt
+    best = min(times)
+    return {"value": n / best / 1e9, "unit": "Gkeys/s", "cores": 1, "kind": kind,
+            "sample": "%d runs of the full %d-key u32 workload, best run %.3f s; host has %d logical cores"
+                      % (len(times), n, best, os.cpu_count() or 0)}, fn
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=N_KEYS, help="keys per GPU (default 64Mi = BASELINE config #2)")
+    ap.add_argument("--algo", type=int, default=None, help="sort.algo override (0 onesweep, 1 three-kernel)")
+    ap.add_argument("--digit-bits", type=int, default=None, help="sort.digit_bits override (8 or 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from oclradixsort_amd import Buffer, DeviceUtils, Pprims, Stopwatch
+    from oclradixsort_amd.adl import Config
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch with that many ranks" % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the device path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.n
+    K, W = args.steps, args.warmup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = {}
+    if world == 1:
+        d = DeviceUtils.allocate(cfg=Config(local_rank))
+        if args.algo is not None:
+            d.setParam("sort.algo", args.algo)
+        if args.digit_bits is not None:
+            d.setParam("sort.digit_bits", args.digit_bits)
+        p = Pprims()
+        bufs = []
+        for i in range(K + W):
+            b = Buffer(d, n, np.uint32)
+            b.generate(n, seed=123 + i)
+            bufs.append(b)
+        DeviceUtils.waitForCompletion(d)
+        for i in range(W):
+            p.radixSort(d, bufs[i], n)
+        DeviceUtils.waitForCompletion(d)
+        barrier()
+        sw = Stopwatch(d)
+        t0 = time.perf_counter()
+        sw.start()
+        for i in range(W, W + K):
+            p.radixSort(d, bufs[i], n)
+        sw.stop()
+        DeviceUtils.waitForCompletion(d)
+        barrier()
+        wall = time.perf_counter() - t0
+        ev_ms = sw.getMs()
+
+        # verification outside the timed region: the first timed batch vs the oracle (bit-exact)
+        verified = None
+        if not args.no_verify:
+            import oracle
+            got = bufs[W].toHost()
+            want = oracle.sort_u32(oracle.keys_u32(n, seed=123 + W))
+            verified = bool(np.array_equal(got, want))
+            if not verified:
+                raise SystemExit("bench: sorted output differs from the oracle")
+
+        # per-kernel durations: profiled loop over fresh random inputs (same seeds regenerated in place)
+        for i in range(W, W + K):
+            bufs[i].generate(n, seed=123 + i)
+        DeviceUtils.waitForCompletion(d)
+        d.toggleProfiling(True)
+        d.profile(reset=True)
+        for i in range(W, W + K):
+            p.radixSort(d, bufs[i], n)
+        prof = d.profile(reset=True)
+        d.toggleProfiling(False)
+
+        # empirical ceilings on this box (copy: read+write, read: read only)
+        probe = {}
+        a, b2 = bufs[0], bufs[1]
+        lib = __import__("oclradixsort_amd._lib", fromlist=["load"]).load()
+        sink = Buffer(d, 2, np.uint64)
+        sink.clear()
+        for name, fn, nbytes in (("copy", lambda: lib.adlhip_probe_copy(d._h, a.ptr(), b2.ptr(), n * 4), 2 * n * 4),
+                                 ("read", lambda: lib.adlhip_probe_read(d._h, a.ptr(), n * 4, sink.ptr()), n * 4)):
+            for _ in range(3):
+                fn()
+            s2 = Stopwatch(d)
+            s2.start()
+            for _ in range(10):
+                fn()
+            s2.stop()
+            probe[name + "_GBps"] = nbytes * 10 / (s2.getMs() * 1e-3) / 1e9
+        sink.release()
+
+        algo = d.getParam("sort.algo")
+        digit_bits = d.getParam("sort.digit_bits")
+        for b in bufs:
+            b.release()
+        p.close()
+        info_name = d.getDeviceName()
+        DeviceUtils.deallocate(d)
+
+        scatter = {k: v for k, v in prof.items() if k.startswith(("onesweep_", "scatter_"))}
+        dom_name, (dom_launches, dom_ms) = max(scatter.items(), key=lambda kv: kv[1][1])
+        dom_avg_s = dom_ms / dom_launches * 1e-3
+        achieved = 2.0 * n * ELEM_BYTES / dom_avg_s / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": dom_name, "launches": dom_launches, "avg_launch_ms": dom_ms / dom_launches,
+            "algorithmic_bytes_per_launch": 2 * n * ELEM_BYTES,
+            "timing": "hipEvent pair around every launch on the library's stream, second loop over the same K inputs",
+        }
+        out["kernels"] = {k: {"launches": v[0], "avg_ms": v[1] / v[0]} for k, v in prof.items()}
+        out["probe"] = probe
+        out["device"] = info_name
+        out["verified_vs_oracle"] = verified
+        out["event_ms_per_step"] = ev_ms / K
+        parallelism = "1 GPU"
+        workload = "Key-only RadixSort32, %d uniform-random u32 keys (splitmix64 hi32, seed 123+step), 1xMI355X, in place" % n
+        cfg_extra = {"sort_algo": "onesweep" if algo == 0 else "three-kernel", "digit_bits": digit_bits}
+    else:
+        from oclradixsort_amd.dist import HipBackend, ShardedRadixSort
+        be = HipBackend(local_rank)
+        if args.algo is not None:
+            be.device.setParam("sort.algo", args.algo)
+        if args.digit_bits is not None:
+            be.device.setParam("sort.digit_bits", args.digit_bits)
+        sorter = ShardedRadixSort(be)
+        inputs = []
+        for i in range(K + W):
+            t = be.empty(n)
+            b = Buffer(dtype=np.uint32)
+            b.setRawPtr(be.device, t.data_ptr(), n)
+            # global index space: rank r owns indices [r*n, (r+1)*n) of step i's key sequence
+            b.generate(n, seed=123 + i, firstIndex=rank * n)
+            inputs.append(t)
+        torch.cuda.synchronize()
+        res = None
+        for i in range(W):
+            res = sorter.sort(inputs[i])
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(W, W + K):
+            res = sorter.sort(inputs[i])
+        barrier()
+        wall = time.perf_counter() - t0
+        verified = None
+        if not args.no_verify:
+            # size-independent checks on the last batch: local sortedness, bucket ownership, global
+            # count and checksum conservation (inputs regenerated for the checksum)
+            x = res.view(torch.int32) ^ (-2147483648)           # order-preserving u32 -> i32 map
+            ok = bool((x[1:] >= x[:-1]).all().item()) if x.numel() > 1 else True
+            shift = 32 - (world.bit_length() - 1)
+            top = (res.to(torch.int64) & 0xffffffff) >> shift
+            ok = ok and bool((top == rank).all().item())
+            cnt = torch.tensor([res.numel(), int((res.to(torch.int64) & 0xffffffff).sum().item())],
+                               dtype=torch.int64, device=res.device)
+            dist.all_reduce(cnt)
+            ref_t = be.empty(n)
+            rb = Buffer(dtype=np.uint32)
+            rb.setRawPtr(be.device, ref_t.data_ptr(), n)
+            rb.generate(n, seed=123 + W + K - 1, firstIndex=rank * n)
+            torch.cuda.synchronize()
+            ref_cnt = torch.tensor([n, int((ref_t.to(torch.int64) & 0xffffffff).sum().item())],
+                                   dtype=torch.int64, device=res.device)
+            dist.all_reduce(ref_cnt)
+            ok = ok and bool((cnt == ref_cnt).all().item())
+            flag = torch.tensor([1 if ok else 0], device=res.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            verified = bool(flag.item())
+            if not verified:
+                raise SystemExit("bench: multi-GPU result failed sortedness/ownership/checksum checks")
+        out["verified_properties"] = verified
+        del inputs, res
+        be.close()
+        parallelism = "msb-bucket x%d (all-to-all over RCCL)" % world
+        workload = "%d uniform-random u32 keys per GPU (weak scaling), MSB-bucket partition + all-to-all + local RadixSort32" % n
+        cfg_extra = {}
+
+    # max over ranks
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    if rank == 0:
+        total_keys = float(n) * world * K
+        value = total_keys / wall / 1e9
+        line = {
+            "metric": "Gkeys/s on uniform-random u32 keys; achieved % of HBM-read roofline",
+            "value": value,
+            "unit": "Gkeys/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": wall / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": dict({"workload": workload, "keys_per_gpu": n, "parallelism": parallelism}, **cfg_extra),
+            # whole-sort fraction under BASELINE.md's definition (96 algorithmic bytes per key per sort)
+            "sort_roofline_frac_96B_per_key": (value / world) * ALGO_BYTES_PER_KEY_SORT / HBM_PEAK_GBS,
+        }
+        line.update(out)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"], _ = cpu_baseline(n)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

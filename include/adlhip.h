@@ -1,0 +1,206 @@
+/*
+ * adlhip.h -- C ABI of the MI355X (gfx950) HIP back-end that replaces the reference's OpenCL
+ * back-end (the Adl/CL directory) and the device half of Tahoe::Pprims for the radix-sort / scan hot path.
+ *
+ * Plain C: opaque handle, raw device pointers, sizes.  No C++ or torch types cross this boundary.
+ * Every function returns ADLHIP_SUCCESS (0) or ADLHIP_FAILURE (1) unless stated otherwise
+ * (the reference defines the same two codes, Adl/Adl.h:22-23, but never returns them: its APIs are
+ * void and fail through ADLASSERT, Tahoe/Math/Error.h:24-38).  Nothing throws across the boundary;
+ * adlhip_last_error() returns the text of the calling thread's most recent failure.
+ *
+ * Threading: like the reference (one in-order command queue per device, Adl/CL/AdlCL.inl:303;
+ * nothing re-entrant), calls on one adlhip_device must be serialised by the caller; distinct handles
+ * may be driven from distinct threads.  All work is enqueued on the handle's one HIP stream and the
+ * primitives return without synchronising, as the GPU branches of Pprims.cpp do.
+ *
+ * All citations are relative to the reference repository root.
+ */
+#ifndef ADLHIP_H
+#define ADLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADLHIP_SUCCESS 0 /* Adl/Adl.h:22 ADL_SUCCESS */
+#define ADLHIP_FAILURE 1 /* Adl/Adl.h:23 ADL_FAILURE */
+
+typedef struct adlhip_device adlhip_device;
+
+/* Replaces Device::getDeviceName/getDeviceVendor/getMemSize/getMaxAllocationSize and
+ * DeviceUtils::getNCUs (Adl/CL/AdlCL.inl:704-759). */
+typedef struct adlhip_info {
+    int32_t compute_units;      /* CL_DEVICE_MAX_COMPUTE_UNITS analogue (AdlCL.inl:704-709) */
+    int32_t wavefront_size;     /* 64 on gfx950 */
+    int32_t lds_bytes_per_cu;   /* sharedMemPerMultiprocessor */
+    int32_t clock_khz;
+    uint64_t total_mem_bytes;
+    uint64_t max_alloc_bytes;
+    char name[128];
+    char arch[64];              /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+    char vendor[32];
+} adlhip_info;
+
+/* ---- device lifetime ----------------------------------------------------------------------- */
+
+/* DeviceUtils::getNDevices(TYPE_CL) -- Adl/Adl.inl:8-23.  Returns the count (0 if none / no driver). */
+int adlhip_device_count(void);
+
+/* DeviceUtils::allocate(TYPE_CL, Config{m_deviceIdx}) -- Adl/Adl.inl:73-98, DeviceCL::initialize
+ * Adl/CL/AdlCL.inl:148-345.  device_idx beyond the last device is clamped to the last one
+ * (AdlCL.inl:244).  Creates one in-order stream. */
+int adlhip_device_create(int device_idx, adlhip_device** out);
+
+/* Same, but enqueue on a caller-owned hipStream_t (e.g. torch's current stream) instead of creating
+ * one.  No reference counterpart; used by the multi-GPU host code so sort and RCCL share a stream. */
+int adlhip_device_create_on_stream(int device_idx, void* hip_stream, adlhip_device** out);
+
+/* DeviceUtils::deallocate -- Adl/Adl.inl:100-105.  Like the reference (ADLASSERT(getUsedMemory()==0))
+ * this FAILS, leaving the handle alive, while adlhip_used_bytes() != 0. */
+int adlhip_device_destroy(adlhip_device* dev);
+
+int adlhip_device_info(adlhip_device* dev, adlhip_info* out);
+
+/* Device::getUsedMemory -- Adl/Adl.h:141; live bytes handed out by adlhip_malloc. */
+uint64_t adlhip_used_bytes(adlhip_device* dev);
+
+/* DeviceUtils::waitForCompletion(const Device*) -- Adl/Adl.inl:107-110 (clFinish, AdlCL.inl:567-570).
+ * Also reports, as a failure, any device-side fault flag a kernel raised since the last sync. */
+int adlhip_sync(adlhip_device* dev);
+
+/* DeviceUtils::flush -- Adl/CL/AdlCL.inl:614-617.  HIP streams need no flush; kept for symmetry. */
+int adlhip_flush(adlhip_device* dev);
+
+/* The stream this handle enqueues on (hipStream_t as void*). */
+void* adlhip_stream(adlhip_device* dev);
+
+const char* adlhip_last_error(void);
+
+/* ---- buffers: Buffer<T> alloc / copies / map -------------------------------------------------- */
+
+/* Buffer<T>::allocate -> DeviceCL::allocate (Adl/CL/AdlCL.inl:356-420): device allocation, accounted
+ * in the live-byte counter.  bytes == 0 yields *dptr == NULL and success. */
+int adlhip_malloc(adlhip_device* dev, size_t bytes, void** dptr);
+/* DeviceCL::deallocate (AdlCL.inl:422-439).  `bytes` must be the size given to adlhip_malloc. */
+int adlhip_free(adlhip_device* dev, void* dptr, size_t bytes);
+
+/* Buffer::write(host)/read(host)/write(Buffer) -- Adl/Adl.inl:273-303, AdlCL.inl:441-510.
+ * Asynchronous and stream-ordered, like the non-blocking clEnqueue* calls they replace: the host
+ * memory must stay valid until adlhip_sync().  Element offsets are folded into the pointers. */
+int adlhip_memcpy_h2d(adlhip_device* dev, void* dst_dev, const void* src_host, size_t bytes);
+int adlhip_memcpy_d2h(adlhip_device* dev, void* dst_host, const void* src_dev, size_t bytes);
+int adlhip_memcpy_d2d(adlhip_device* dev, void* dst_dev, const void* src_dev, size_t bytes);
+
+/* Buffer::clear / fill -- Adl/Adl.inl:305-315, AdlCL.inl:512-542 (byte-wise / 4-byte pattern). */
+int adlhip_memset(adlhip_device* dev, void* dptr, int byte_value, size_t bytes);
+int adlhip_fill_u32(adlhip_device* dev, void* dptr, uint32_t pattern, size_t count);
+
+/* Buffer::getHostPtr / returnHostPtr -- Adl/Adl.inl:317-329, AdlCL.inl:544-565 (non-blocking
+ * clEnqueueMapBuffer READ|WRITE / clEnqueueUnmapMemObject).  adlhip_map enqueues a device->pinned-host
+ * copy and returns the host pointer; contents are valid after adlhip_sync().  adlhip_unmap enqueues the
+ * host->device write-back and releases the staging memory once that copy has run; the device sees the
+ * writes after adlhip_sync().  Exactly the call sequence of UnitTest/main.cpp:118-125. */
+int adlhip_map(adlhip_device* dev, void* dptr, size_t bytes, void** hptr);
+int adlhip_unmap(adlhip_device* dev, void* dptr, void* hptr, size_t bytes);
+
+/* ---- the primitives: Tahoe::Pprims ----------------------------------------------------------- */
+
+/* Element kinds the sort entry points handle. */
+#define ADLHIP_ELEM_U32  0 /* Buffer<u32>   : Pprims::radixSort(..., Buffer<u32>&, ...)   Pprims.h:41 */
+#define ADLHIP_ELEM_KV32 1 /* Buffer<uint2> : {x = key, y = value}                         Pprims.h:38 */
+#define ADLHIP_ELEM_U64  2 /* 64-bit keys (BASELINE config #5; no reference API)                       */
+
+/* Scratch the caller must own, replacing Pprims' m_u32WorkBuffer[0] (ping-pong copy of the data,
+ * Pprims.cpp:226-232, :332) and m_u32WorkBuffer[1] (histogram table, :229-230, :333-337).
+ *   *tmp_bytes  : second data buffer, n elements
+ *   *work_bytes : control scratch (digit tables / tile status words), depends on n and the device */
+int adlhip_radix_sort_scratch_bytes(adlhip_device* dev, int elem_kind, size_t n,
+                                    size_t* tmp_bytes, size_t* work_bytes);
+
+/* Pprims::radixSort(const Device*, const Buffer<u32>& inout, int n, int sortBits=32)
+ * -- Tahoe/ParallelPrimitives/Pprims.h:41, Pprims.cpp:304-406.
+ * Sorts d_keys_inout[0..n) ascending by the low `sort_bits` bits of each key, stably with respect to
+ * input order; the result is in d_keys_inout (odd pass counts are copied back, Pprims.cpp:400-403).
+ * sort_bits: multiple of 4 in [4,32] (Pprims.cpp:330); anything else fails.  Unlike the reference
+ * (n % 256 == 0, Pprims.cpp:327) any n >= 0 is accepted.  Enqueues and returns. */
+int adlhip_radix_sort_u32(adlhip_device* dev, uint32_t* d_keys_inout, uint32_t* d_tmp,
+                          void* d_work, size_t work_bytes, size_t n, int sort_bits);
+
+/* Pprims::radixSort(const Device*, const Buffer<uint2>& inout, int n, int sortBits=32)
+ * -- Pprims.h:38, Pprims.cpp:200-302.  Elements are 8-byte {u32 key (.x); u32 value (.y)} pairs
+ * (Tahoe/Math/Math.h:175-188 == SortData, Tahoe/Algorithm/Sort/RadixSort.h:10-27); stable. */
+int adlhip_radix_sort_kv32(adlhip_device* dev, void* d_pairs_inout, void* d_tmp,
+                           void* d_work, size_t work_bytes, size_t n, int sort_bits);
+
+/* 64-bit keys, ascending; sort_bits multiple of 4 in [4,64]. */
+int adlhip_radix_sort_u64(adlhip_device* dev, uint64_t* d_keys_inout, uint64_t* d_tmp,
+                          void* d_work, size_t work_bytes, size_t n, int sort_bits);
+
+/* Pprims::scan(const Device*, Buffer<int>& dst, const Buffer<int>& src, int n, u32* sumOut=0)
+ * -- Pprims.h:35, Pprims.cpp:122-179.  Exclusive prefix sum, 32-bit wrap-around.  dst may equal src.
+ * h_sum_or_null: when non-NULL the grand total is copied there (stream-ordered; valid after
+ * adlhip_sync(), like the reference's non-blocking read at Pprims.cpp:164-167).  No n < 1,048,576
+ * limit (the reference silently returns for numBlocks >= 4096, Pprims.cpp:134-138). */
+int adlhip_scan_scratch_bytes(adlhip_device* dev, size_t n, size_t* work_bytes);
+int adlhip_exclusive_scan_u32(adlhip_device* dev, uint32_t* d_dst, const uint32_t* d_src,
+                              void* d_work, size_t work_bytes, size_t n, uint32_t* h_sum_or_null);
+
+/* ---- multi-GPU helper: MSB-bucket partition (no reference counterpart) ----- */
+
+/* Stable partition of n u32 keys into `num_buckets` (<= 256, power of two) contiguous segments by
+ * their top log2(num_buckets) bits; d_counts_out[num_buckets] (u32) receives the segment sizes.
+ * This is one radix pass on the most significant digit: the send side of the all-to-all exchange. */
+int adlhip_partition_msb_u32(adlhip_device* dev, const uint32_t* d_keys_in, uint32_t* d_keys_out,
+                             uint32_t* d_counts_out, void* d_work, size_t work_bytes,
+                             size_t n, int num_buckets);
+
+/* ---- synthetic inputs: generated in place, reproducible by index ---------- */
+
+/* key32(i) = hi32(splitmix64(seed*0x9E3779B97F4A7C15 + first_index + i)); key64 = the full 64 bits;
+ * KV32 pair = {key32(i), value = (u32)(first_index + i)} (value = original index, as
+ * UnitTest/main.cpp:152 does, so stability is checkable).  elem_kind: ADLHIP_ELEM_*. */
+int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n, uint64_t seed,
+                         uint64_t first_index);
+
+/* ---- knobs ---------------------------------------------------------------------------------- */
+
+/* Integer tunables, by name.  Unknown names fail.  Current names:
+ *   "sort.algo"        0 = onesweep (single-pass per digit, decoupled look-back)  [default]
+ *                      1 = three kernels per pass: count -> table scan -> sort+scatter (the
+ *                          reference's pass structure, Pprims.cpp:357-398)
+ *   "sort.digit_bits"  8 [default] or 4 (4 = the reference's R32SORT_BITS_PER_PASS, Pprims.h:31)
+ *   "profile"          0/1: bracket every kernel launch with hipEvents (Device::toggleProfiling,
+ *                          Adl/Adl.h:142, AdlKernelUtilsCL.inl:654-677) */
+int adlhip_set_param(adlhip_device* dev, const char* name, int value);
+int adlhip_get_param(adlhip_device* dev, const char* name, int* value);
+
+/* ---- timing / profiling ----------------------------------------------------------------------- */
+
+/* adl::Stopwatch (Adl/AdlStopwatch.h:60-83) on the handle's stream: start/split/stop map onto
+ * hipEvent records; elapsed is device time between two recorded events. */
+typedef struct adlhip_event adlhip_event;
+int adlhip_event_create(adlhip_device* dev, adlhip_event** out);
+int adlhip_event_record(adlhip_device* dev, adlhip_event* ev);
+int adlhip_event_elapsed_ms(adlhip_device* dev, adlhip_event* start, adlhip_event* stop, float* ms);
+int adlhip_event_destroy(adlhip_device* dev, adlhip_event* ev);
+
+/* Per-kernel launch timing collected while "profile" = 1 (replaces the per-launch CSV rows of
+ * Adl/CL/AdlKernelUtilsCL.inl:664-677).  adlhip_profile_count synchronises the stream and folds the
+ * pending event pairs; entry i is then readable with adlhip_profile_get. */
+int adlhip_profile_reset(adlhip_device* dev);
+int adlhip_profile_count(adlhip_device* dev);
+int adlhip_profile_get(adlhip_device* dev, int i, char name_out[64], uint64_t* launches, double* total_ms);
+
+/* ---- bandwidth probes (diagnostics for bench.py: empirical HBM ceilings) ---------------------- */
+int adlhip_probe_copy(adlhip_device* dev, void* d_dst, const void* d_src, size_t bytes);
+int adlhip_probe_read(adlhip_device* dev, const void* d_src, size_t bytes, void* d_sink8);
+
+const char* adlhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADLHIP_H */

@@ -1,0 +1,857 @@
+// adlhip.hip -- implementation of include/adlhip.h: the HIP back-end behind the Adl/Pprims facade.
+// Replaces Adl/CL/AdlCL.inl (device, buffers, copies, map/unmap), Adl/CL/AdlKernelUtilsCL.inl
+// (kernel launch + per-launch profiling) and the GPU branches of Tahoe/ParallelPrimitives/Pprims.cpp
+// (pass drivers).  gfx950 only; kernels are compiled ahead of time into this shared object.
+#include "../../include/adlhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "radix_kernels.hpp"
+#include "onesweep_kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    if (getenv("ADLHIP_VERBOSE")) fprintf(stderr, "[adlhip] error: %s\n", g_err);
+    return ADLHIP_FAILURE;
+}
+
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct ProfEntry {
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+};
+struct PendingProf {
+    const char* name;
+    hipEvent_t e0, e1;
+};
+struct Staging {
+    void* hptr;
+    size_t bytes;
+    hipEvent_t done;   // null while mapped; set at unmap
+};
+
+}  // namespace
+
+struct adlhip_event {
+    hipEvent_t ev;
+};
+
+struct adlhip_device {
+    int idx = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    hipDeviceProp_t prop;
+    uint64_t used_bytes = 0;
+    // knobs
+    int sort_algo = 0;        // 0 onesweep, 1 three-kernel pass
+    int digit_bits = 8;       // 8 or 4
+    int profile = 0;
+    // profiling
+    std::vector<PendingProf> pending;
+    std::vector<hipEvent_t> event_pool;
+    std::map<std::string, ProfEntry> prof;
+    std::vector<std::string> prof_order;
+    // map/unmap staging
+    std::vector<Staging> staging;
+    // device-side fault word (look-back timeout etc.), checked at sync
+    uint32_t* d_fault = nullptr;
+    uint32_t* h_fault = nullptr;   // pinned
+};
+
+namespace {
+
+int bind(adlhip_device* d)
+{
+    if (!d) return fail("null device handle");
+    HIPCHK(hipSetDevice(d->idx));
+    return ADLHIP_SUCCESS;
+}
+
+hipEvent_t take_event(adlhip_device* d)
+{
+    if (!d->event_pool.empty()) {
+        hipEvent_t e = d->event_pool.back();
+        d->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+// Launch wrapper: optional hipEvent bracket per launch ("profile" = 1), error check after.
+template <typename F>
+int launch(adlhip_device* d, const char* name, F&& f)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (d->profile) {
+        e0 = take_event(d);
+        e1 = take_event(d);
+        if (!e0 || !e1) return fail("hipEventCreate failed");
+        HIPCHK(hipEventRecord(e0, d->stream));
+    }
+    f();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("launch of %s failed: %s", name, hipGetErrorString(e));
+    if (d->profile) {
+        HIPCHK(hipEventRecord(e1, d->stream));
+        d->pending.push_back({name, e0, e1});
+    }
+    return ADLHIP_SUCCESS;
+}
+
+int fold_profile(adlhip_device* d)
+{
+    if (d->pending.empty()) return ADLHIP_SUCCESS;
+    HIPCHK(hipStreamSynchronize(d->stream));
+    for (auto& p : d->pending) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, p.e0, p.e1));
+        auto it = d->prof.find(p.name);
+        if (it == d->prof.end()) {
+            d->prof_order.push_back(p.name);
+            it = d->prof.emplace(p.name, ProfEntry()).first;
+        }
+        it->second.launches++;
+        it->second.total_ms += ms;
+        d->event_pool.push_back(p.e0);
+        d->event_pool.push_back(p.e1);
+    }
+    d->pending.clear();
+    return ADLHIP_SUCCESS;
+}
+
+void reap_staging(adlhip_device* d, bool all_done)
+{
+    for (size_t i = 0; i < d->staging.size();) {
+        Staging& s = d->staging[i];
+        if (s.done && (all_done || hipEventQuery(s.done) == hipSuccess)) {
+            hipEventDestroy(s.done);
+            hipHostFree(s.hptr);
+            d->staging[i] = d->staging.back();
+            d->staging.pop_back();
+        } else {
+            ++i;
+        }
+    }
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- sort configuration -------------------------------------------------------------------
+
+// Tile geometry per element size (threads per block NT, items per thread K).
+//   4-byte elements: 256 x 16 = 4096 keys  (16 KiB of LDS staging)
+//   8-byte elements: 256 x 16 = 4096 elems (32 KiB)
+constexpr int kNT = 256;
+constexpr int kK = 16;
+constexpr uint32_t kTile = kNT * kK;
+constexpr int kWgsPerCu = 8;   // three-kernel pass: resident workgroups per CU that own runs of tiles
+
+struct PassPlan {
+    int start_bit;
+    int nbits;
+};
+
+std::vector<PassPlan> plan_passes(int sort_bits, int digit_bits)
+{
+    std::vector<PassPlan> p;
+    int sb = 0;
+    while (sb < sort_bits) {
+        int nb = (digit_bits == 8 && sort_bits - sb >= 8) ? 8 : 4;
+        p.push_back({sb, nb});
+        sb += nb;
+    }
+    return p;
+}
+
+struct Geometry {
+    uint32_t num_tiles, tiles_per_wg, n_wgs;
+};
+
+Geometry geometry(const adlhip_device* d, size_t n)
+{
+    Geometry g;
+    g.num_tiles = (uint32_t)((n + kTile - 1) / kTile);
+    const uint32_t max_wgs = (uint32_t)d->prop.multiProcessorCount * kWgsPerCu;
+    g.tiles_per_wg = (g.num_tiles + max_wgs - 1) / max_wgs;
+    if (g.tiles_per_wg == 0) g.tiles_per_wg = 1;
+    g.n_wgs = (g.num_tiles + g.tiles_per_wg - 1) / g.tiles_per_wg;
+    return g;
+}
+
+constexpr size_t kMaxElems = 0xFFF00000ull;   // 32-bit element indices inside the kernels
+
+// work buffer layout (three-kernel pass): [table 256 x n_wgs u32][totals 256 u32]
+size_t work_bytes_three_kernel(const adlhip_device* d, size_t n)
+{
+    Geometry g = geometry(d, n);
+    return align_up((size_t)256 * g.n_wgs * 4, 256) + 256 * 4;
+}
+
+template <typename E, int NBITS>
+int three_kernel_pass(adlhip_device* d, const E* src, E* dst, void* work, size_t n, int start_bit)
+{
+    using C = adlhip::TileCfg<E, NBITS, kNT, kK>;
+    const Geometry g = geometry(d, n);
+    uint32_t* table = reinterpret_cast<uint32_t*>(work);
+    uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + align_up((size_t)256 * g.n_wgs * 4, 256));
+    const uint32_t elems_per_wg = g.tiles_per_wg * kTile;
+    int rc;
+    rc = launch(d, NBITS == 8 ? (sizeof(E) == 4 ? "count_u32_8b" : "count_e64_8b") : (sizeof(E) == 4 ? "count_u32_4b" : "count_e64_4b"), [&] {
+        hipLaunchKernelGGL((adlhip::radix_count_kernel<E, NBITS, kNT>), dim3(g.n_wgs), dim3(kNT), 0, d->stream,
+                           src, table, (uint32_t)n, (int)g.n_wgs, start_bit, elems_per_wg);
+    });
+    if (rc) return rc;
+    rc = launch(d, "scan_table", [&] {
+        hipLaunchKernelGGL((adlhip::radix_scan_table_kernel<256>), dim3(C::BINS), dim3(256), 0, d->stream,
+                           table, totals, (int)g.n_wgs);
+    });
+    if (rc) return rc;
+    rc = launch(d, NBITS == 8 ? (sizeof(E) == 4 ? "scatter_u32_8b" : "scatter_e64_8b") : (sizeof(E) == 4 ? "scatter_u32_4b" : "scatter_e64_4b"), [&] {
+        hipLaunchKernelGGL((adlhip::radix_scatter_kernel<E, NBITS, kNT, kK>), dim3(g.n_wgs), dim3(kNT),
+                           C::LDS_BYTES, d->stream, src, dst, table, totals, (uint32_t)n, (int)g.n_wgs,
+                           start_bit, g.tiles_per_wg, g.num_tiles);
+    });
+    return rc;
+}
+
+// ---- onesweep --------------------------------------------------------------------------------
+
+// work buffer layout (onesweep):
+//   [ctrl: per pass {ticket u32} padded to 64 B ... 16 passes = 1024 B]
+//   [ghist: 16 passes x 256 u32 global digit bases]
+//   [partial hist: hist_wgs x passes x 256 u32]
+//   [status: passes x num_tiles x 256 u32]
+struct OnesweepLayout {
+    size_t off_ctrl, off_ghist, off_part, off_status, total;
+    uint32_t hist_wgs, num_tiles;
+    int max_passes;
+};
+
+OnesweepLayout onesweep_layout(const adlhip_device* d, size_t n, int max_passes)
+{
+    OnesweepLayout L;
+    L.max_passes = max_passes;
+    L.num_tiles = (uint32_t)((n + adlhip::kOsTile - 1) / adlhip::kOsTile);
+    if (L.num_tiles == 0) L.num_tiles = 1;
+    const uint32_t cap = (uint32_t)d->prop.multiProcessorCount * 4;
+    L.hist_wgs = std::min<uint32_t>(cap, (uint32_t)((n + adlhip::kHistChunk - 1) / adlhip::kHistChunk));
+    if (L.hist_wgs == 0) L.hist_wgs = 1;
+    L.off_ctrl = 0;
+    L.off_ghist = 1024;
+    L.off_part = L.off_ghist + (size_t)16 * 256 * 4;
+    L.off_status = align_up(L.off_part + (size_t)L.hist_wgs * max_passes * 256 * 4, 256);
+    L.total = L.off_status + (size_t)max_passes * L.num_tiles * 256 * 4;
+    return L;
+}
+
+template <typename E>
+int onesweep_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, const std::vector<PassPlan>& plan)
+{
+    const int P = (int)plan.size();
+    const OnesweepLayout L = onesweep_layout(d, n, (int)(sizeof(E) == 4 ? 8 : 16));
+    char* wb = reinterpret_cast<char*>(work);
+    uint32_t* ctrl = reinterpret_cast<uint32_t*>(wb + L.off_ctrl);
+    uint32_t* ghist = reinterpret_cast<uint32_t*>(wb + L.off_ghist);
+    uint32_t* part = reinterpret_cast<uint32_t*>(wb + L.off_part);
+    uint32_t* status = reinterpret_cast<uint32_t*>(wb + L.off_status);
+
+    // zero tickets + every status word of the passes we run (one memset; status is contiguous)
+    HIPCHK(hipMemsetAsync(ctrl, 0, 1024, d->stream));
+    HIPCHK(hipMemsetAsync(status, 0, (size_t)P * L.num_tiles * 256 * 4, d->stream));
+
+    adlhip::PassDesc desc;
+    desc.num_passes = P;
+    for (int i = 0; i < P; ++i) {
+        desc.start_bit[i] = (uint8_t)plan[i].start_bit;
+        desc.nbits[i] = (uint8_t)plan[i].nbits;
+    }
+    int rc;
+    const uint32_t chunk = (uint32_t)align_up((n + L.hist_wgs - 1) / L.hist_wgs, 1024);
+    rc = launch(d, sizeof(E) == 4 ? "os_hist_u32" : "os_hist_e64", [&] {
+        hipLaunchKernelGGL((adlhip::onesweep_hist_kernel<E>), dim3(L.hist_wgs), dim3(adlhip::kHistNT), 0, d->stream,
+                           data, part, (uint32_t)n, chunk, desc);
+    });
+    if (rc) return rc;
+    rc = launch(d, "os_hist_reduce", [&] {
+        hipLaunchKernelGGL(adlhip::onesweep_hist_reduce_kernel, dim3(P), dim3(256), 0, d->stream,
+                           part, ghist, L.hist_wgs, P);
+    });
+    if (rc) return rc;
+
+    E* src = data;
+    E* dst = tmp;
+    for (int i = 0; i < P; ++i) {
+        uint32_t* st = status + (size_t)i * L.num_tiles * 256;
+        const int sb = plan[i].start_bit;
+        if (plan[i].nbits == 8) {
+            using C = adlhip::TileCfg<E, 8, adlhip::kOsNT, adlhip::kOsK>;
+            rc = launch(d, sizeof(E) == 4 ? "onesweep_u32_8b" : "onesweep_e64_8b", [&] {
+                hipLaunchKernelGGL((adlhip::onesweep_pass_kernel<E, 8, adlhip::kOsNT, adlhip::kOsK>),
+                                   dim3(L.num_tiles), dim3(adlhip::kOsNT), C::LDS_BYTES, d->stream, src, dst,
+                                   ghist + i * 256, st, ctrl + i * 16, d->d_fault, (uint32_t)n, sb, L.num_tiles);
+            });
+        } else {
+            using C = adlhip::TileCfg<E, 4, adlhip::kOsNT, adlhip::kOsK>;
+            rc = launch(d, sizeof(E) == 4 ? "onesweep_u32_4b" : "onesweep_e64_4b", [&] {
+                hipLaunchKernelGGL((adlhip::onesweep_pass_kernel<E, 4, adlhip::kOsNT, adlhip::kOsK>),
+                                   dim3(L.num_tiles), dim3(adlhip::kOsNT), C::LDS_BYTES, d->stream, src, dst,
+                                   ghist + i * 256, st, ctrl + i * 16, d->d_fault, (uint32_t)n, sb, L.num_tiles);
+            });
+        }
+        if (rc) return rc;
+        std::swap(src, dst);
+    }
+    if (src != data) HIPCHK(hipMemcpyAsync(data, src, n * sizeof(E), hipMemcpyDeviceToDevice, d->stream));
+    return ADLHIP_SUCCESS;
+}
+
+template <typename E>
+int three_kernel_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, const std::vector<PassPlan>& plan)
+{
+    E* src = data;
+    E* dst = tmp;
+    for (const PassPlan& p : plan) {
+        int rc = (p.nbits == 8) ? three_kernel_pass<E, 8>(d, src, dst, work, n, p.start_bit)
+                                : three_kernel_pass<E, 4>(d, src, dst, work, n, p.start_bit);
+        if (rc) return rc;
+        std::swap(src, dst);   // Pprims.cpp:397
+    }
+    // odd number of passes: result sits in the scratch buffer -> copy back (Pprims.cpp:400-403)
+    if (src != data) HIPCHK(hipMemcpyAsync(data, src, n * sizeof(E), hipMemcpyDeviceToDevice, d->stream));
+    return ADLHIP_SUCCESS;
+}
+
+size_t sort_work_bytes(const adlhip_device* d, int elem_kind, size_t n)
+{
+    const size_t a = work_bytes_three_kernel(d, n);
+    const size_t b = onesweep_layout(d, n, elem_kind == ADLHIP_ELEM_U64 ? 16 : 8).total;
+    return std::max(a, b);
+}
+
+template <typename E>
+int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, size_t work_bytes, size_t n,
+               int sort_bits, int max_bits)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (sort_bits < 4 || sort_bits > max_bits || (sort_bits & 3))   // Pprims.cpp:330
+        return fail("sort_bits must be a multiple of 4 in [4,%d], got %d", max_bits, sort_bits);
+    if (n == 0) return ADLHIP_SUCCESS;
+    if (n > kMaxElems) return fail("n = %zu exceeds the supported maximum %zu", n, (size_t)kMaxElems);
+    if (!data || !tmp || !work) return fail("null buffer passed to radix sort");
+    if ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(tmp)) & 15u)
+        return fail("sort buffers must be 16-byte aligned");
+    const size_t need = sort_work_bytes(d, elem_kind, n);
+    if (work_bytes < need) return fail("work buffer too small: %zu < %zu", work_bytes, need);
+    const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
+    // tile status words carry 30-bit counts: beyond 2^30 elements use the table-based pass
+    if (d->sort_algo == 1 || n >= (size_t(1) << 30)) return three_kernel_sort<E>(d, data, tmp, work, n, plan);
+    return onesweep_sort<E>(d, data, tmp, work, n, plan);
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* adlhip_version(void) { return "adlhip 0.1 (gfx950)"; }
+const char* adlhip_last_error(void) { return g_err; }
+
+int adlhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int create_common(int device_idx, void* stream, bool own, adlhip_device** out)
+{
+    if (!out) return fail("null out pointer");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail("no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device_idx < 0) device_idx = 0;
+    if (device_idx >= n) device_idx = n - 1;   // AdlCL.inl:244 clamps the same way
+    adlhip_device* d = new adlhip_device();
+    d->idx = device_idx;
+    if (hipSetDevice(device_idx) != hipSuccess || hipGetDeviceProperties(&d->prop, device_idx) != hipSuccess) {
+        delete d;
+        return fail("cannot bind HIP device %d", device_idx);
+    }
+    if (strncmp(d->prop.gcnArchName, "gfx950", 6) != 0 && !getenv("ADLHIP_ALLOW_ANY_ARCH")) {
+        std::string arch = d->prop.gcnArchName;
+        delete d;
+        return fail("adlhip is built for gfx950 only; device %d is %s", device_idx, arch.c_str());
+    }
+    d->own_stream = own;
+    if (own) {
+        if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete d;
+            return fail("hipStreamCreate failed");
+        }
+    } else {
+        d->stream = reinterpret_cast<hipStream_t>(stream);
+    }
+    if (hipMalloc(&d->d_fault, 64) != hipSuccess || hipHostMalloc(&d->h_fault, 64) != hipSuccess ||
+        hipMemsetAsync(d->d_fault, 0, 64, d->stream) != hipSuccess) {
+        delete d;
+        return fail("cannot allocate the fault word");
+    }
+    if (const char* a = getenv("ADLHIP_SORT_ALGO")) d->sort_algo = atoi(a);
+    if (const char* b = getenv("ADLHIP_DIGIT_BITS")) d->digit_bits = (atoi(b) == 4) ? 4 : 8;
+    *out = d;
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_device_create(int device_idx, adlhip_device** out) { return create_common(device_idx, nullptr, true, out); }
+
+int adlhip_device_create_on_stream(int device_idx, void* hip_stream, adlhip_device** out)
+{
+    return create_common(device_idx, hip_stream, false, out);
+}
+
+int adlhip_device_destroy(adlhip_device* d)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (d->used_bytes != 0)   // Adl.inl:102 ADLASSERT( getUsedMemory() == 0 )
+        return fail("device still has %llu live bytes; free every buffer first", (unsigned long long)d->used_bytes);
+    hipStreamSynchronize(d->stream);
+    reap_staging(d, true);
+    for (auto& s : d->staging) hipHostFree(s.hptr);
+    for (auto& p : d->pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
+    for (auto e : d->event_pool) hipEventDestroy(e);
+    hipFree(d->d_fault);
+    hipHostFree(d->h_fault);
+    if (d->own_stream) hipStreamDestroy(d->stream);
+    delete d;
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_device_info(adlhip_device* d, adlhip_info* out)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!out) return fail("null info pointer");
+    memset(out, 0, sizeof(*out));
+    out->compute_units = d->prop.multiProcessorCount;
+    out->wavefront_size = d->prop.warpSize;
+    out->lds_bytes_per_cu = (int32_t)d->prop.maxSharedMemoryPerMultiProcessor;
+    out->clock_khz = d->prop.clockRate;
+    out->total_mem_bytes = d->prop.totalGlobalMem;
+    out->max_alloc_bytes = d->prop.totalGlobalMem;
+    snprintf(out->name, sizeof(out->name), "%s", d->prop.name);
+    snprintf(out->arch, sizeof(out->arch), "%s", d->prop.gcnArchName);
+    snprintf(out->vendor, sizeof(out->vendor), "Advanced Micro Devices, Inc.");
+    return ADLHIP_SUCCESS;
+}
+
+uint64_t adlhip_used_bytes(adlhip_device* d) { return d ? d->used_bytes : 0; }
+
+void* adlhip_stream(adlhip_device* d) { return d ? (void*)d->stream : nullptr; }
+
+int adlhip_sync(adlhip_device* d)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    // pick up the device-side fault word together with the drain
+    HIPCHK(hipMemcpyAsync(d->h_fault, d->d_fault, 4, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    reap_staging(d, true);
+    if (d->h_fault[0] != 0) {
+        const uint32_t code = d->h_fault[0];
+        d->h_fault[0] = 0;
+        hipMemsetAsync(d->d_fault, 0, 4, d->stream);
+        return fail("device-side fault 0x%x (look-back wait exceeded its bound); results are invalid", code);
+    }
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_flush(adlhip_device* d) { return bind(d); }
+
+int adlhip_malloc(adlhip_device* d, size_t bytes, void** dptr)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!dptr) return fail("null out pointer");
+    *dptr = nullptr;
+    if (bytes == 0) return ADLHIP_SUCCESS;
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) {   // AdlCL.inl:390-406: log, leave m_ptr = 0
+        *dptr = nullptr;
+        return fail("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    d->used_bytes += bytes;
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_free(adlhip_device* d, void* dptr, size_t bytes)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!dptr) return ADLHIP_SUCCESS;
+    HIPCHK(hipStreamSynchronize(d->stream));   // queued work may still use it
+    HIPCHK(hipFree(dptr));
+    d->used_bytes -= std::min<uint64_t>(bytes, d->used_bytes);
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_memcpy_h2d(adlhip_device* d, void* dst, const void* src, size_t bytes)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (bytes == 0) return ADLHIP_SUCCESS;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream));
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_memcpy_d2h(adlhip_device* d, void* dst, const void* src, size_t bytes)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (bytes == 0) return ADLHIP_SUCCESS;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, d->stream));
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_memcpy_d2d(adlhip_device* d, void* dst, const void* src, size_t bytes)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (bytes == 0) return ADLHIP_SUCCESS;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, d->stream));
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_memset(adlhip_device* d, void* dptr, int byte_value, size_t bytes)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (bytes == 0) return ADLHIP_SUCCESS;
+    HIPCHK(hipMemsetAsync(dptr, byte_value, bytes, d->stream));
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_fill_u32(adlhip_device* d, void* dptr, uint32_t pattern, size_t count)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (count == 0) return ADLHIP_SUCCESS;
+    const int grid = (int)std::min<size_t>((count + 255) / 256, (size_t)d->prop.multiProcessorCount * 8);
+    return launch(d, "fill_u32", [&] {
+        hipLaunchKernelGGL(adlhip::fill_u32_kernel, dim3(grid), dim3(256), 0, d->stream, (uint32_t*)dptr, pattern, count);
+    });
+}
+
+int adlhip_map(adlhip_device* d, void* dptr, size_t bytes, void** hptr)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!hptr) return fail("null out pointer");
+    *hptr = nullptr;
+    reap_staging(d, false);
+    if (bytes == 0) return ADLHIP_SUCCESS;
+    void* h = nullptr;
+    HIPCHK(hipHostMalloc(&h, bytes));
+    hipError_t e = hipMemcpyAsync(h, dptr, bytes, hipMemcpyDeviceToHost, d->stream);
+    if (e != hipSuccess) {
+        hipHostFree(h);
+        return fail("map: device->host copy failed: %s", hipGetErrorString(e));
+    }
+    d->staging.push_back({h, bytes, nullptr});
+    *hptr = h;
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_unmap(adlhip_device* d, void* dptr, void* hptr, size_t bytes)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!hptr) return ADLHIP_SUCCESS;
+    for (auto& s : d->staging) {
+        if (s.hptr == hptr && !s.done) {
+            if (bytes > s.bytes) return fail("unmap: %zu bytes exceeds the mapped %zu", bytes, s.bytes);
+            HIPCHK(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, d->stream));
+            hipEvent_t ev;
+            HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(ev, d->stream));
+            s.done = ev;
+            return ADLHIP_SUCCESS;
+        }
+    }
+    return fail("unmap: pointer %p was not returned by adlhip_map", hptr);
+}
+
+// ---- sort ---------------------------------------------------------------------------------------
+
+int adlhip_radix_sort_scratch_bytes(adlhip_device* d, int elem_kind, size_t n, size_t* tmp_bytes, size_t* work_bytes)
+{
+    if (!d) return fail("null device handle");
+    if (elem_kind < ADLHIP_ELEM_U32 || elem_kind > ADLHIP_ELEM_U64) return fail("bad element kind %d", elem_kind);
+    const size_t esz = elem_kind == ADLHIP_ELEM_U32 ? 4 : 8;
+    if (tmp_bytes) *tmp_bytes = align_up(n * esz, 256);
+    if (work_bytes) *work_bytes = sort_work_bytes(d, elem_kind, n);
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_radix_sort_u32(adlhip_device* d, uint32_t* keys, uint32_t* tmp, void* work, size_t work_bytes, size_t n, int sort_bits)
+{
+    return sort_entry<uint32_t>(d, ADLHIP_ELEM_U32, keys, tmp, work, work_bytes, n, sort_bits, 32);
+}
+
+int adlhip_radix_sort_kv32(adlhip_device* d, void* pairs, void* tmp, void* work, size_t work_bytes, size_t n, int sort_bits)
+{
+    return sort_entry<uint64_t>(d, ADLHIP_ELEM_KV32, (uint64_t*)pairs, (uint64_t*)tmp, work, work_bytes, n, sort_bits, 32);
+}
+
+int adlhip_radix_sort_u64(adlhip_device* d, uint64_t* keys, uint64_t* tmp, void* work, size_t work_bytes, size_t n, int sort_bits)
+{
+    return sort_entry<uint64_t>(d, ADLHIP_ELEM_U64, keys, tmp, work, work_bytes, n, sort_bits, 64);
+}
+
+// ---- scan ---------------------------------------------------------------------------------------
+
+int adlhip_scan_scratch_bytes(adlhip_device* d, size_t n, size_t* work_bytes)
+{
+    if (!d) return fail("null device handle");
+    const size_t blocks = (n + adlhip::kScanTile - 1) / adlhip::kScanTile;
+    if (work_bytes) *work_bytes = align_up((blocks + 2) * 4, 256);
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_exclusive_scan_u32(adlhip_device* d, uint32_t* dst, const uint32_t* src, void* work, size_t work_bytes,
+                              size_t n, uint32_t* h_sum)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    size_t need = 0;
+    adlhip_scan_scratch_bytes(d, n, &need);
+    if (work_bytes < need || !work) return fail("scan work buffer too small: %zu < %zu", work_bytes, need);
+    uint32_t* partial = reinterpret_cast<uint32_t*>(work);
+    if (n == 0) {
+        if (h_sum) *h_sum = 0;
+        return ADLHIP_SUCCESS;
+    }
+    if (!dst || !src) return fail("null buffer passed to scan");
+    const size_t blocks = (n + adlhip::kScanTile - 1) / adlhip::kScanTile;
+    if (blocks > 0x7fffffffull) return fail("scan: n too large");
+    uint32_t* d_total = partial + blocks;   // grand total lives behind the block sums
+    int rc;
+    if (blocks <= 8) {
+        rc = launch(d, "scan_single", [&] {
+            hipLaunchKernelGGL(adlhip::scan_single_kernel, dim3(1), dim3(adlhip::kScanNT), 0, d->stream, src, dst, n, d_total);
+        });
+        if (rc) return rc;
+    } else {
+        rc = launch(d, "scan_reduce", [&] {
+            hipLaunchKernelGGL(adlhip::scan_reduce_kernel, dim3((uint32_t)blocks), dim3(adlhip::kScanNT), 0, d->stream, src, partial, n);
+        });
+        if (rc) return rc;
+        rc = launch(d, "scan_partials", [&] {
+            hipLaunchKernelGGL(adlhip::scan_single_kernel, dim3(1), dim3(adlhip::kScanNT), 0, d->stream,
+                               (const uint32_t*)partial, partial, blocks, d_total);
+        });
+        if (rc) return rc;
+        rc = launch(d, "scan_apply", [&] {
+            hipLaunchKernelGGL(adlhip::scan_apply_kernel, dim3((uint32_t)blocks), dim3(adlhip::kScanNT), 0, d->stream,
+                               src, dst, (const uint32_t*)partial, n);
+        });
+        if (rc) return rc;
+    }
+    if (h_sum) HIPCHK(hipMemcpyAsync(h_sum, d_total, 4, hipMemcpyDeviceToHost, d->stream));   // Pprims.cpp:164-167
+    return ADLHIP_SUCCESS;
+}
+
+// ---- MSB partition (multi-GPU send side) -----------------------------------------------------------
+
+int adlhip_partition_msb_u32(adlhip_device* d, const uint32_t* in, uint32_t* out, uint32_t* counts, void* work,
+                             size_t work_bytes, size_t n, int num_buckets)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    int lg = 0;
+    while ((1 << lg) < num_buckets) ++lg;
+    if (num_buckets < 1 || num_buckets > 256 || (1 << lg) != num_buckets)
+        return fail("num_buckets must be a power of two in [1,256], got %d", num_buckets);
+    if (!counts) return fail("null counts pointer");
+    if (n > kMaxElems) return fail("n too large");
+    if (n == 0 || num_buckets == 1) {
+        HIPCHK(hipMemsetAsync(counts, 0, 4 * (size_t)num_buckets, d->stream));
+        if (n) {
+            HIPCHK(hipMemcpyAsync(out, in, n * 4, hipMemcpyDeviceToDevice, d->stream));
+            uint32_t nn = (uint32_t)n;
+            // counts[0] = n  (stream-ordered fill of one word)
+            int rc = launch(d, "fill_u32", [&] {
+                hipLaunchKernelGGL(adlhip::fill_u32_kernel, dim3(1), dim3(256), 0, d->stream, counts, nn, (size_t)1);
+            });
+            if (rc) return rc;
+        }
+        return ADLHIP_SUCCESS;
+    }
+    const size_t need = work_bytes_three_kernel(d, n);
+    if (work_bytes < need || !work) return fail("work buffer too small: %zu < %zu", work_bytes, need);
+    if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) return fail("buffers must be 16-byte aligned");
+    // one three-kernel pass on the top byte (the top `lg` bits decide the bucket; ordering by the
+    // whole top byte refines buckets without mixing them), then fold the 256 digit totals into buckets
+    int rc = three_kernel_pass<uint32_t, 8>(d, in, out, work, n, 24);
+    if (rc) return rc;
+    const Geometry g = geometry(d, n);
+    uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + align_up((size_t)256 * g.n_wgs * 4, 256));
+    return launch(d, "fold_buckets", [&] {
+        hipLaunchKernelGGL(adlhip::fold_buckets_kernel, dim3(1), dim3(256), 0, d->stream, (const uint32_t*)totals, counts, num_buckets);
+    });
+}
+
+// ---- synthetic inputs ---------------------------------------------------------------------------
+
+int adlhip_generate_keys(adlhip_device* d, int elem_kind, void* dptr, size_t n, uint64_t seed, uint64_t first_index)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (elem_kind < ADLHIP_ELEM_U32 || elem_kind > ADLHIP_ELEM_U64) return fail("bad element kind %d", elem_kind);
+    if (n == 0) return ADLHIP_SUCCESS;
+    if (!dptr) return fail("null buffer");
+    const uint64_t base = seed * 0x9E3779B97F4A7C15ull + first_index;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)d->prop.multiProcessorCount * 16);
+    return launch(d, "generate_keys", [&] {
+        hipLaunchKernelGGL(adlhip::generate_keys_kernel, dim3(grid), dim3(256), 0, d->stream, dptr, n, base, first_index, elem_kind);
+    });
+}
+
+// ---- knobs ------------------------------------------------------------------------------------
+
+int adlhip_set_param(adlhip_device* d, const char* name, int value)
+{
+    if (!d || !name) return fail("null argument");
+    if (!strcmp(name, "sort.algo")) {
+        if (value != 0 && value != 1) return fail("sort.algo must be 0 or 1");
+        d->sort_algo = value;
+    } else if (!strcmp(name, "sort.digit_bits")) {
+        if (value != 4 && value != 8) return fail("sort.digit_bits must be 4 or 8");
+        d->digit_bits = value;
+    } else if (!strcmp(name, "profile")) {
+        if (bind(d)) return ADLHIP_FAILURE;
+        if (!value && fold_profile(d)) return ADLHIP_FAILURE;
+        d->profile = value ? 1 : 0;
+    } else {
+        return fail("unknown parameter '%s'", name);
+    }
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_get_param(adlhip_device* d, const char* name, int* value)
+{
+    if (!d || !name || !value) return fail("null argument");
+    if (!strcmp(name, "sort.algo")) *value = d->sort_algo;
+    else if (!strcmp(name, "sort.digit_bits")) *value = d->digit_bits;
+    else if (!strcmp(name, "profile")) *value = d->profile;
+    else return fail("unknown parameter '%s'", name);
+    return ADLHIP_SUCCESS;
+}
+
+// ---- events / profiling ---------------------------------------------------------------------------
+
+int adlhip_event_create(adlhip_device* d, adlhip_event** out)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!out) return fail("null out pointer");
+    adlhip_event* e = new adlhip_event();
+    if (hipEventCreate(&e->ev) != hipSuccess) {
+        delete e;
+        return fail("hipEventCreate failed");
+    }
+    *out = e;
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_event_record(adlhip_device* d, adlhip_event* ev)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!ev) return fail("null event");
+    HIPCHK(hipEventRecord(ev->ev, d->stream));
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_event_elapsed_ms(adlhip_device* d, adlhip_event* a, adlhip_event* b, float* ms)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!a || !b || !ms) return fail("null argument");
+    HIPCHK(hipEventSynchronize(b->ev));
+    HIPCHK(hipEventElapsedTime(ms, a->ev, b->ev));
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_event_destroy(adlhip_device* d, adlhip_event* ev)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!ev) return ADLHIP_SUCCESS;
+    hipEventDestroy(ev->ev);
+    delete ev;
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_profile_reset(adlhip_device* d)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (fold_profile(d)) return ADLHIP_FAILURE;
+    d->prof.clear();
+    d->prof_order.clear();
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_profile_count(adlhip_device* d)
+{
+    if (bind(d)) return -1;
+    if (fold_profile(d)) return -1;
+    return (int)d->prof_order.size();
+}
+
+int adlhip_profile_get(adlhip_device* d, int i, char name_out[64], uint64_t* launches, double* total_ms)
+{
+    if (!d) return fail("null device handle");
+    if (i < 0 || i >= (int)d->prof_order.size()) return fail("profile index %d out of range", i);
+    const std::string& nm = d->prof_order[i];
+    const ProfEntry& e = d->prof[nm];
+    if (name_out) snprintf(name_out, 64, "%s", nm.c_str());
+    if (launches) *launches = e.launches;
+    if (total_ms) *total_ms = e.total_ms;
+    return ADLHIP_SUCCESS;
+}
+
+// ---- probes ---------------------------------------------------------------------------------------
+
+int adlhip_probe_copy(adlhip_device* d, void* dst, const void* src, size_t bytes)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    const size_t nvec = bytes / 16;
+    if (nvec == 0) return ADLHIP_SUCCESS;
+    const int grid = (int)std::min<size_t>((nvec + 255) / 256, (size_t)d->prop.multiProcessorCount * 8);
+    return launch(d, "probe_copy", [&] {
+        hipLaunchKernelGGL(adlhip::probe_copy_kernel, dim3(grid), dim3(256), 0, d->stream, (uint4*)dst, (const uint4*)src, nvec);
+    });
+}
+
+int adlhip_probe_read(adlhip_device* d, const void* src, size_t bytes, void* sink8)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    const size_t nvec = bytes / 16;
+    if (nvec == 0) return ADLHIP_SUCCESS;
+    const int grid = (int)std::min<size_t>((nvec + 255) / 256, (size_t)d->prop.multiProcessorCount * 8);
+    return launch(d, "probe_read", [&] {
+        hipLaunchKernelGGL(adlhip::probe_read_kernel, dim3(grid), dim3(256), 0, d->stream, (const uint4*)src, nvec,
+                           (unsigned long long*)sink8);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+"""Python mirror of `Tahoe::Pprims` (Tahoe/ParallelPrimitives/Pprims.h:11-48) over the HIP back-end.
+
+    p = Pprims()
+    p.radixSort(device, buffer_u32, n, sortBits=32)        # Pprims.h:41
+    p.radixSort(device, buffer_uint2, n, sortBits=32)      # Pprims.h:38  (dtype uint64 = {key, value})
+    p.radixSort64(device, buffer_u64, n, sortBits=64)      # 64-bit keys (no reference counterpart)
+    p.scan(device, dst, src, n, sumOut=None)               # Pprims.h:35
+
+Like the reference object it owns lazily grown device scratch (m_u32WorkBuffer[0] = ping-pong data
+buffer, m_u32WorkBuffer[1] = histogram table; Pprims.h:44-45, Pprims.cpp:226-232, :332-337) and must be
+destroyed (close()) before DeviceUtils.deallocate, which refuses while memory is live (Adl.inl:102).
+Calls enqueue and return without synchronising, as the reference's GPU branches do.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import AdlHipError, check
+from .adl import Buffer
+
+ELEM_U32 = 0
+ELEM_KV32 = 1
+ELEM_U64 = 2
+
+
+class Pprims:
+    SCAN_BLOCK_SIZE = 128               # Pprims.h:24 (kept for API parity; unused by the HIP kernels)
+    R32SORT_DATA_ALIGNMENT = 256        # Pprims.h:28: the reference needs n % 256 == 0; this build does not
+    R32SORT_WG_SIZE = 64                # Pprims.h:29
+    R32SORT_BITS_PER_PASS = 4           # Pprims.h:31: available via device.setParam("sort.digit_bits", 4)
+
+    def __init__(self):
+        self.m_tmp = None       # m_u32WorkBuffer[0]
+        self.m_work = None      # m_u32WorkBuffer[1]
+        self.m_cacheKernel = True
+        self._sum_keep = None
+
+    def cacheKernel(self, cache):   # Pprims.h:20 -- kernels are compiled ahead of time; nothing to cache
+        self.m_cacheKernel = bool(cache)
+
+    def close(self):
+        for b in (self.m_tmp, self.m_work):
+            if b is not None:
+                b.release()
+        self.m_tmp = self.m_work = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- scratch (uArray::setSize semantics: grow-only, contents not preserved)
+    def _scratch(self, device, tmp_bytes, work_bytes):
+        if self.m_tmp is None or self.m_tmp.m_device is not device:
+            self.close()
+            self.m_tmp = Buffer(device, 0, np.uint8)
+            self.m_work = Buffer(device, 0, np.uint8)
+        if self.m_tmp.getSize() < tmp_bytes:
+            self.m_tmp.setSize(tmp_bytes)
+        if self.m_work.getSize() < work_bytes:
+            self.m_work.setSize(work_bytes)
+
+    def _sort(self, device, kind, fn, inout, n, sortBits):
+        if device is None:
+            raise AdlHipError("radixSort needs a device (the Python mirror has no host fallback)")
+        n = int(n)
+        lib = _lib.load()
+        tb = ctypes.c_size_t()
+        wb = ctypes.c_size_t()
+        check(lib.adlhip_radix_sort_scratch_bytes(device._h, kind, n, ctypes.byref(tb), ctypes.byref(wb)),
+              "adlhip_radix_sort_scratch_bytes")
+        self._scratch(device, tb.value, wb.value)
+        check(fn(device._h, inout.ptr(), self.m_tmp.ptr(), self.m_work.ptr(), self.m_work.getSize(), n, int(sortBits)),
+              "radixSort")
+
+    def radixSort(self, device, inout, n, sortBits=32):
+        """u32 keys (dtype uint32) or {u32 key, u32 value} pairs (dtype uint64, key in the low dword)."""
+        lib = _lib.load()
+        if inout.dtype == np.uint32:
+            self._sort(device, ELEM_U32, lib.adlhip_radix_sort_u32, inout, n, sortBits)
+        elif inout.dtype == np.uint64:
+            self._sort(device, ELEM_KV32, lib.adlhip_radix_sort_kv32, inout, n, sortBits)
+        else:
+            raise AdlHipError("radixSort: unsupported element type %s" % inout.dtype)
+
+    def radixSort64(self, device, inout, n, sortBits=64):
+        assert inout.dtype == np.uint64
+        self._sort(device, ELEM_U64, _lib.load().adlhip_radix_sort_u64, inout, n, sortBits)
+
+    def scan(self, device, dst, src, n, sumOut=None):
+        """Exclusive prefix sum.  sumOut: optional 1-element uint32 numpy array that receives the grand
+        total once the caller has synchronised (Pprims.cpp:164-167 reads it back non-blocking too)."""
+        if device is None:
+            raise AdlHipError("scan needs a device")   # Pprims.cpp:124-127 ADLASSERT(0)
+        lib = _lib.load()
+        wb = ctypes.c_size_t()
+        check(lib.adlhip_scan_scratch_bytes(device._h, int(n), ctypes.byref(wb)), "adlhip_scan_scratch_bytes")
+        self._scratch(device, 0, wb.value)
+        hp = None
+        if sumOut is not None:
+            assert sumOut.dtype == np.uint32 and sumOut.size >= 1
+            self._sum_keep = sumOut
+            hp = sumOut.ctypes.data_as(ctypes.c_void_p)
+        check(lib.adlhip_exclusive_scan_u32(device._h, dst.ptr(), src.ptr(), self.m_work.ptr(), self.m_work.getSize(),
+                                            int(n), hp), "scan")

@@ -1,0 +1,379 @@
+"""GPU parity tests (run with `-m gpu` on the MI355X box).  Everything goes through the C ABI
+(libadlhip.so via ctypes); expectations come from the oracle and from the committed golden vectors.
+Integer work: the bar is bit-exact.
+
+Mirrors the reference's test (UnitTest/main.cpp:40-56, 88-213: Demo.Sort32 / Demo.SortKeyValue /
+Demo.Scan over 11 doubling sizes with srand(123) data) and adds what it lacks:
+low-entropy keys, ragged n, partial sortBits, n = 0, scan >= 1M, scratch reuse, 64-bit keys.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oclradixsort_amd import AdlHipError, Buffer, DeviceUtils, Pprims, Stopwatch
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = [(0, 8), (0, 4), (1, 8), (1, 4)]   # (sort.algo, sort.digit_bits)
+ALGO_IDS = ["onesweep8", "onesweep4", "threekernel8", "threekernel4"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    d = DeviceUtils.allocate()
+    yield d
+    DeviceUtils.deallocate(d)
+
+
+@pytest.fixture()
+def pp(dev):
+    dev.setParam("sort.algo", 0)
+    dev.setParam("sort.digit_bits", 8)
+    p = Pprims()
+    yield p
+    p.close()
+
+
+def set_algo(dev, algo):
+    dev.setParam("sort.algo", algo[0])
+    dev.setParam("sort.digit_bits", algo[1])
+
+
+def gpu_sort_u32(dev, p, keys, bits=32):
+    b = Buffer(dev, keys.size, np.uint32)
+    b.write(keys)
+    p.radixSort(dev, b, keys.size, bits)
+    out = b.toHost()
+    b.release()
+    return out
+
+
+def gpu_sort_kv(dev, p, pairs, bits=32):
+    b = Buffer(dev, pairs.size, np.uint64)
+    b.write(pairs)
+    p.radixSort(dev, b, pairs.size, bits)
+    out = b.toHost()
+    b.release()
+    return out
+
+
+def gpu_sort_u64(dev, p, keys, bits=64):
+    b = Buffer(dev, keys.size, np.uint64)
+    b.write(keys)
+    p.radixSort64(dev, b, keys.size, bits)
+    out = b.toHost()
+    b.release()
+    return out
+
+
+def gpu_scan(dev, p, vals, want_total=False):
+    src = Buffer(dev, vals.size, np.uint32)
+    dst = Buffer(dev, vals.size, np.uint32)
+    src.write(vals)
+    total = np.zeros(1, dtype=np.uint32) if want_total else None
+    p.scan(dev, dst, src, vals.size, total)
+    out = dst.toHost()
+    src.release()
+    dst.release()
+    return (out, int(total[0])) if want_total else out
+
+
+# ---------------------------------------------------------------------------------------------
+# device / buffer plumbing (the boundary)
+# ---------------------------------------------------------------------------------------------
+def test_device_is_mi355x(dev):
+    assert dev.info.arch.decode().startswith("gfx950")
+    assert dev.info.wavefront_size == 64
+    assert DeviceUtils.getNCUs(dev) >= 1
+    assert DeviceUtils.getNDevices() >= 1
+
+
+def test_buffer_roundtrip_map_unmap_and_accounting(dev):
+    base = dev.getUsedMemory()
+    n = 100000
+    b = Buffer(dev, n, np.uint32)
+    assert dev.getUsedMemory() == base + 4 * n
+    data = oracle.keys_u32(n, 99)
+    # fill through getHostPtr / returnHostPtr exactly as UnitTest/main.cpp:118-125 does
+    h = b.getHostPtr(n)
+    DeviceUtils.waitForCompletion(dev)
+    h[:] = data
+    b.returnHostPtr(h)
+    DeviceUtils.waitForCompletion(dev)
+    assert np.array_equal(b.toHost(), data)
+    # offset write / read
+    b.write(np.arange(10, dtype=np.uint32), 10, 5)
+    got = np.empty(10, dtype=np.uint32)
+    b.read(got, 10, 5)
+    DeviceUtils.waitForCompletion(dev)
+    assert np.array_equal(got, np.arange(10, dtype=np.uint32))
+    # device-to-device
+    c = Buffer(dev, n, np.uint32)
+    c.write(b, n)
+    assert np.array_equal(c.toHost(), b.toHost())
+    # deallocate refuses while memory is live (Adl.inl:102)
+    d2 = DeviceUtils.allocate()
+    bb = Buffer(d2, 16, np.uint32)
+    with pytest.raises(AdlHipError):
+        DeviceUtils.deallocate(d2)
+    bb.release()
+    DeviceUtils.deallocate(d2)
+    b.release()
+    c.release()
+    assert dev.getUsedMemory() == base
+
+
+def test_bad_arguments_fail_loudly(dev, pp):
+    b = Buffer(dev, 1024, np.uint32)
+    for bits in (0, 3, 6, 36, -4):
+        with pytest.raises(AdlHipError):
+            pp.radixSort(dev, b, 1024, bits)     # Pprims.cpp:330: (sortBits & 3) == 0
+    with pytest.raises(AdlHipError):
+        dev.setParam("sort.algo", 7)
+    with pytest.raises(AdlHipError):
+        dev.setParam("no.such.param", 1)
+    b.release()
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's three Demo tests, all 11 sizes, checked against the oracle AND the golden table
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def table(golden_dir):
+    with open(os.path.join(golden_dir, "demo_table.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS)
+def test_demo_sort32(dev, pp, table, algo):
+    set_algo(dev, algo)
+    for row in table["sort32"]:          # 1K ... 1024K, UnitTest/main.cpp:105
+        n = row["n"]
+        keys = oracle.demo_u32(n)        # seedRandom(123) per size, main.cpp:109
+        got = gpu_sort_u32(dev, pp, keys)
+        assert np.array_equal(got, oracle.sort_u32(keys)), n
+        if "%016x" % oracle.fnv1a64(keys) == row["fnv_in"]:
+            assert "%016x" % oracle.fnv1a64(got) == row["fnv_out"], n
+
+
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS)
+def test_demo_sort_key_value(dev, pp, table, algo):
+    set_algo(dev, algo)
+    for row in table["sortkv"]:          # 1037 ... 1075187 (testSize += 13, main.cpp:144)
+        n = row["n"]
+        pairs = oracle.demo_kv32(n)
+        got = gpu_sort_kv(dev, pp, pairs)
+        assert np.array_equal(got, oracle.sort_kv32(pairs)), n       # key AND value: stability
+        if "%016x" % oracle.fnv1a64(pairs) == row["fnv_in"]:
+            assert "%016x" % oracle.fnv1a64(got) == row["fnv_out"], n
+
+
+def test_demo_scan_including_1024k(dev, pp, table):
+    for row in table["scan"]:            # the reference fails at 1024K by design (README.md:73-74)
+        n = row["n"]
+        vals = oracle.demo_scan(n)
+        got, total = gpu_scan(dev, pp, vals, want_total=True)
+        want, wtotal = oracle.exclusive_scan_u32(vals)
+        assert np.array_equal(got, want), n
+        assert total == wtotal == row["total"], n
+        if "%016x" % oracle.fnv1a64(vals) == row["fnv_in"]:
+            assert "%016x" % oracle.fnv1a64(got) == row["fnv_out"], n
+
+
+# ---------------------------------------------------------------------------------------------
+# golden adversarial vectors produced by the reference itself
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS)
+def test_adversarial_golden(dev, pp, golden_dir, algo):
+    set_algo(dev, algo)
+    adv = np.load(os.path.join(golden_dir, "adversarial.npz"))
+    names = sorted(k[len("u32_in_"):] for k in adv.files if k.startswith("u32_in_"))
+    for nm in names:
+        assert np.array_equal(gpu_sort_u32(dev, pp, adv["u32_in_" + nm]), adv["u32_out_" + nm]), nm
+        assert np.array_equal(gpu_sort_kv(dev, pp, adv["kv_in_" + nm]), adv["kv_out_" + nm]), nm
+
+
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS)
+def test_small_demo_golden_vectors(dev, pp, golden_dir, algo):
+    set_algo(dev, algo)
+    small = np.load(os.path.join(golden_dir, "demo_small.npz"))
+    for n in (1024, 2048):
+        assert np.array_equal(gpu_sort_u32(dev, pp, small["sort32_in_%d" % n]), small["sort32_out_%d" % n])
+    for m in (1037, 2087):
+        assert np.array_equal(gpu_sort_kv(dev, pp, small["sortkv_in_%d" % m]), small["sortkv_out_%d" % m])
+    assert np.array_equal(gpu_scan(dev, pp, small["scan_in_1024"]), small["scan_out_1024"])
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases the reference never tests
+# ---------------------------------------------------------------------------------------------
+RAGGED = [0, 1, 2, 63, 64, 65, 255, 256, 257, 1023, 4095, 4096, 4097, 8191, 8193, 12289, 65537, 262143, 1000003]
+
+
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS)
+def test_ragged_sizes_u32_kv_u64(dev, pp, algo):
+    set_algo(dev, algo)
+    for n in RAGGED:
+        k = oracle.keys_u32(n, seed=n + 1)
+        assert np.array_equal(gpu_sort_u32(dev, pp, k), oracle.sort_u32(k)), n
+        p = oracle.pairs_kv32(n, seed=n + 2)
+        assert np.array_equal(gpu_sort_kv(dev, pp, p), oracle.sort_kv32(p)), n
+        k64 = oracle.keys_u64(n, seed=n + 3)
+        assert np.array_equal(gpu_sort_u64(dev, pp, k64), oracle.sort_u64(k64)), n
+
+
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS)
+def test_low_entropy_and_stability(dev, pp, algo):
+    set_algo(dev, algo)
+    rng = np.random.RandomState(3)
+    n = 300007
+    cases = {
+        "all_equal": np.full(n, 0xabcdef01, dtype=np.uint64),
+        "all_max": np.full(n, 0xffffffff, dtype=np.uint64),
+        "all_zero": np.zeros(n, dtype=np.uint64),
+        "two_values": rng.randint(0, 2, n).astype(np.uint64) * 0xffffffff,
+        "low_byte": rng.randint(0, 256, n).astype(np.uint64),
+        "one_nibble_each": rng.randint(0, 16, n).astype(np.uint64) * 0x11111111,
+        "sorted": np.sort(rng.randint(0, 2**32, n, dtype=np.uint64)),
+        "reverse": np.sort(rng.randint(0, 2**32, n, dtype=np.uint64))[::-1].copy(),
+        "same_digit_per_tile": (np.arange(n, dtype=np.uint64) // 4096) & 0xff,
+    }
+    for nm, keys in cases.items():
+        k32 = keys.astype(np.uint32)
+        assert np.array_equal(gpu_sort_u32(dev, pp, k32), oracle.sort_u32(k32)), nm
+        pairs = keys | (np.arange(n, dtype=np.uint64) << 32)    # value = original index
+        assert np.array_equal(gpu_sort_kv(dev, pp, pairs), oracle.sort_kv32(pairs)), nm
+
+
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS)
+def test_partial_sort_bits(dev, pp, algo):
+    """sortBits < 32: only the low bits are ordered, stably (Pprims.cpp:357); odd pass counts exercise the
+    copy-back (Pprims.cpp:400-403)."""
+    set_algo(dev, algo)
+    n = 70001
+    k = oracle.keys_u32(n, seed=5)
+    p = oracle.pairs_kv32(n, seed=6)
+    for bits in range(4, 33, 4):
+        assert np.array_equal(gpu_sort_u32(dev, pp, k, bits), oracle.sort_u32_bits(k, bits)), bits
+        assert np.array_equal(gpu_sort_kv(dev, pp, p, bits), oracle.sort_e64_bits(p, bits)), bits
+    k64 = oracle.keys_u64(n, seed=8)
+    for bits in (4, 28, 36, 48, 60, 64):
+        assert np.array_equal(gpu_sort_u64(dev, pp, k64, bits), oracle.sort_e64_bits(k64, bits)), bits
+
+
+def test_scratch_reuse_growing_and_shrinking(dev, pp):
+    for n in (5000, 2000000, 300, 70000, 2000000, 1):
+        k = oracle.keys_u32(n, seed=n)
+        assert np.array_equal(gpu_sort_u32(dev, pp, k), oracle.sort_u32(k)), n
+        p = oracle.pairs_kv32(n, seed=n)
+        assert np.array_equal(gpu_sort_kv(dev, pp, p), oracle.sort_kv32(p)), n
+
+
+def test_scan_sizes_and_inplace(dev, pp):
+    rng = np.random.RandomState(1)
+    for n in (0, 1, 2, 255, 4096, 4097, 32768, 32769, 1 << 20, (1 << 22) + 12345):
+        v = rng.randint(0, 2**32, n, dtype=np.uint64).astype(np.uint32)   # wrap-around arithmetic
+        got, total = gpu_scan(dev, pp, v, want_total=True)
+        want, wtotal = oracle.exclusive_scan_u32(v)
+        assert np.array_equal(got, want), n
+        assert total == wtotal, n
+    n = 1 << 21
+    v = oracle.demo_scan(n)
+    b = Buffer(dev, n, np.uint32)
+    b.write(v)
+    pp.scan(dev, b, b, n)            # dst == src
+    assert np.array_equal(b.toHost(), oracle.exclusive_scan_u32(v)[0])
+    b.release()
+
+
+def test_lookback_under_repeated_uneven_launches(dev, pp):
+    """Hammer the tile-status protocol: many back-to-back sorts of different sizes on one stream, checked
+    only at the end (no sync in between), plus a fault-word check at sync."""
+    set_algo(dev, (0, 8))
+    sizes = [1 << 20, 777777, 4097, 3 << 20, 123456, 5 << 20, 65536]
+    bufs, wants = [], []
+    for i, n in enumerate(sizes):
+        k = oracle.keys_u32(n, seed=100 + i)
+        b = Buffer(dev, n, np.uint32)
+        b.write(k)
+        bufs.append(b)
+        wants.append(oracle.sort_u32(k))
+    DeviceUtils.waitForCompletion(dev)
+    for rep in range(3):
+        for b, n in zip(bufs, sizes):
+            pp.radixSort(dev, b, n)      # re-sorting sorted data is also a valid (idempotence) check
+    DeviceUtils.waitForCompletion(dev)   # raises if a look-back wait hit its bound
+    for b, w in zip(bufs, wants):
+        assert np.array_equal(b.toHost(), w)
+        b.release()
+
+
+# ---------------------------------------------------------------------------------------------
+# full BASELINE sizes: size-independent properties (sortedness, multiset checksum, stability)
+# ---------------------------------------------------------------------------------------------
+def _checksums(a):
+    a64 = a.astype(np.uint64) if a.dtype != np.uint64 else a
+    return int(a64.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(a64)), int((a64 * a64).sum(dtype=np.uint64))
+
+
+@pytest.mark.parametrize("algo", [(0, 8), (1, 8)], ids=["onesweep8", "threekernel8"])
+def test_full_size_64m_u32(dev, pp, algo):
+    set_algo(dev, algo)
+    n = 1 << 26
+    keys = oracle.keys_u32(n, seed=123)
+    got = gpu_sort_u32(dev, pp, keys)
+    assert np.all(got[1:] >= got[:-1])
+    assert _checksums(got) == _checksums(keys)
+    # spot-check a prefix and a suffix bit-exactly against the oracle on the exact multiset
+    want = oracle.sort_u32(keys)
+    assert np.array_equal(got, want)
+    # idempotence: sorting the sorted array changes nothing
+    assert np.array_equal(gpu_sort_u32(dev, pp, got), got)
+
+
+def test_full_size_64m_key_value(dev, pp):
+    n = 1 << 26
+    pairs = oracle.pairs_kv32(n, seed=123) & np.uint64(0xffffffff00ffffff)   # 24-bit keys -> duplicates
+    got = gpu_sort_kv(dev, pp, pairs)
+    k = (got & np.uint64(0xffffffff))
+    v = (got >> np.uint64(32))
+    assert np.all(k[1:] >= k[:-1])
+    same = k[1:] == k[:-1]
+    assert same.any()
+    assert np.all(v[1:][same] > v[:-1][same])          # stability: original index increases within a key
+    assert _checksums(got) == _checksums(pairs)
+    assert np.array_equal(got, oracle.sort_kv32(pairs))
+
+
+def test_full_size_256m_u64(dev, pp):
+    n = 1 << 28
+    keys = oracle.keys_u64(n, seed=123)
+    got = gpu_sort_u64(dev, pp, keys)
+    assert np.all(got[1:] >= got[:-1])
+    assert _checksums(got) == _checksums(keys)
+    del keys
+    # a second, independent run must give the identical array (determinism)
+    again = gpu_sort_u64(dev, pp, oracle.keys_u64(n, seed=123))
+    assert np.array_equal(got, again)
+
+
+def test_stopwatch_and_profiling(dev, pp):
+    n = 1 << 22
+    b = Buffer(dev, n, np.uint32)
+    b.write(oracle.keys_u32(n, 1))
+    sw = Stopwatch(dev)
+    dev.toggleProfiling(True)
+    dev.profile(reset=True)
+    sw.start()
+    pp.radixSort(dev, b, n)
+    sw.stop()
+    ms = sw.getMs()
+    prof = dev.profile(reset=True)
+    dev.toggleProfiling(False)
+    assert ms > 0
+    assert any(k.startswith("onesweep_u32") for k in prof), prof
+    assert sum(v[1] for v in prof.values()) > 0
+    b.release()
