@@ -172,6 +172,11 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      1 = three kernels per pass: count -> table scan -> sort+scatter (the
  *                          reference's pass structure, Pprims.cpp:357-398)
  *   "sort.digit_bits"  8 [default] or 4 (4 = the reference's R32SORT_BITS_PER_PASS, Pprims.h:31)
+ *   "sort.tile"        tile geometry variant (threads x elements per thread): 0 = 256x16 [default],
+ *                      1 = 512x16, 2 = 1024x16, 3 = 512x8, 4 = 1024x8, 5 = 256x32
+ *   "sort.rank"        1 [default when the device self-test passes] = in-tile ranking by lane-ordered
+ *                      returning LDS atomics; 0 = ranking by 64-lane ballot match
+ *   "sort.lds_ordered" (read-only) result of that self-test
  *   "profile"          0/1: bracket every kernel launch with hipEvents (Device::toggleProfiling,
  *                          Adl/Adl.h:142, AdlKernelUtilsCL.inl:654-677) */
 int adlhip_set_param(adlhip_device* dev, const char* name, int value);

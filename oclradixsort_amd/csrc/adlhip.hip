@@ -69,6 +69,9 @@ struct adlhip_device {
     int sort_algo = 0;        // 0 onesweep, 1 three-kernel pass
     int digit_bits = 8;       // 8 or 4
     int profile = 0;
+    int tile_variant = 0;     // index into kVariants
+    int rank_mode = 1;        // 1 = lane-ordered DS atomic ranking (needs lds_ordered), 0 = ballot match
+    int lds_ordered = 0;      // result of the device self-test at creation
     // profiling
     std::vector<PendingProf> pending;
     std::vector<hipEvent_t> event_pool;
@@ -163,13 +166,16 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- sort configuration -------------------------------------------------------------------
 
-// Tile geometry per element size (threads per block NT, items per thread K).
-//   4-byte elements: 256 x 16 = 4096 keys  (16 KiB of LDS staging)
-//   8-byte elements: 256 x 16 = 4096 elems (32 KiB)
-constexpr int kNT = 256;
-constexpr int kK = 16;
-constexpr uint32_t kTile = kNT * kK;
-constexpr int kWgsPerCu = 8;   // three-kernel pass: resident workgroups per CU that own runs of tiles
+// Tile geometry variants (threads per workgroup NT x elements per thread K), selectable at run time
+// through "sort.tile".  Scratch is always sized for the smallest tile (kMinTile) so that changing the
+// variant never invalidates a caller's work buffer.
+struct TileVariant {
+    int nt, k;
+};
+constexpr TileVariant kVariants[] = {{256, 16}, {512, 16}, {1024, 16}, {512, 8}, {1024, 8}, {256, 32}};
+constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+constexpr uint32_t kMinTile = 4096;
+constexpr int kWgsPerCu = 8;   // three-kernel pass: workgroups per CU that each own a run of tiles
 
 struct PassPlan {
     int start_bit;
@@ -189,13 +195,14 @@ std::vector<PassPlan> plan_passes(int sort_bits, int digit_bits)
 }
 
 struct Geometry {
-    uint32_t num_tiles, tiles_per_wg, n_wgs;
+    uint32_t tile, num_tiles, tiles_per_wg, n_wgs;
 };
 
-Geometry geometry(const adlhip_device* d, size_t n)
+Geometry geometry(const adlhip_device* d, size_t n, uint32_t tile)
 {
     Geometry g;
-    g.num_tiles = (uint32_t)((n + kTile - 1) / kTile);
+    g.tile = tile;
+    g.num_tiles = (uint32_t)((n + tile - 1) / tile);
     const uint32_t max_wgs = (uint32_t)d->prop.multiProcessorCount * kWgsPerCu;
     g.tiles_per_wg = (g.num_tiles + max_wgs - 1) / max_wgs;
     if (g.tiles_per_wg == 0) g.tiles_per_wg = 1;
@@ -203,86 +210,178 @@ Geometry geometry(const adlhip_device* d, size_t n)
     return g;
 }
 
+uint32_t current_tile(const adlhip_device* d) { return (uint32_t)(kVariants[d->tile_variant].nt * kVariants[d->tile_variant].k); }
+
 constexpr size_t kMaxElems = 0xFFF00000ull;   // 32-bit element indices inside the kernels
 
 // work buffer layout (three-kernel pass): [table 256 x n_wgs u32][totals 256 u32]
-size_t work_bytes_three_kernel(const adlhip_device* d, size_t n)
+size_t table_bytes(const adlhip_device* d, size_t n, uint32_t tile)
 {
-    Geometry g = geometry(d, n);
-    return align_up((size_t)256 * g.n_wgs * 4, 256) + 256 * 4;
+    return align_up((size_t)256 * geometry(d, n, tile).n_wgs * 4, 256);
+}
+size_t work_bytes_three_kernel(const adlhip_device* d, size_t n) { return table_bytes(d, n, kMinTile) + 256 * 4; }
+
+// Kernels with more than 64 KiB of dynamic LDS need the limit raised once per function.
+template <typename KernelT>
+int ensure_lds(KernelT kernel, size_t bytes)
+{
+    static size_t raised_to = 0;   // one instance per kernel instantiation (KernelT is a distinct fn type only
+                                   // per signature, so key on the pointer as well)
+    static const void* raised_for = nullptr;
+    if (bytes <= 64 * 1024) return ADLHIP_SUCCESS;
+    if (raised_for == (const void*)kernel && raised_to >= bytes) return ADLHIP_SUCCESS;
+    HIPCHK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    raised_for = (const void*)kernel;
+    raised_to = bytes;
+    return ADLHIP_SUCCESS;
+}
+
+// Interned kernel names (the profiler keeps the pointer until the events are folded).
+const char* intern(const std::string& s)
+{
+    static std::map<std::string, std::string*> pool;
+    auto it = pool.find(s);
+    if (it == pool.end()) it = pool.emplace(s, new std::string(s)).first;
+    return it->second->c_str();
+}
+
+template <typename E, int NBITS>
+const char* kernel_name(const char* stem)
+{
+    return intern(std::string(stem) + (sizeof(E) == 4 ? "_u32" : "_e64") + (NBITS == 8 ? "_8b" : "_4b"));
+}
+
+// ---- three-kernel pass: count -> table scan -> sort+scatter --------------------------------------
+
+template <typename E, int NBITS, int NT, int K, int RANK>
+int launch_scatter(adlhip_device* d, const E* src, E* dst, const uint32_t* table, const uint32_t* totals, size_t n,
+                   const Geometry& g, int start_bit)
+{
+    using C = adlhip::TileCfg<E, NBITS, NT, K>;
+    auto kern = adlhip::radix_scatter_kernel<E, NBITS, NT, K, RANK>;
+    if (ensure_lds(kern, C::LDS_BYTES)) return ADLHIP_FAILURE;
+    return launch(d, kernel_name<E, NBITS>("scatter"), [&] {
+        hipLaunchKernelGGL(kern, dim3(g.n_wgs), dim3(NT), C::LDS_BYTES, d->stream, src, dst, table, totals, (uint32_t)n,
+                           (int)g.n_wgs, start_bit, g.tiles_per_wg, g.num_tiles);
+    });
+}
+
+#define ADLHIP_DISPATCH_TILE(FN, E, NBITS, ...)                                                     \
+    switch (d->tile_variant * 2 + (d->rank_mode ? 1 : 0)) {                                         \
+    case 0: return FN<E, NBITS, 256, 16, 0>(__VA_ARGS__);                                           \
+    case 1: return FN<E, NBITS, 256, 16, 1>(__VA_ARGS__);                                           \
+    case 2: return FN<E, NBITS, 512, 16, 0>(__VA_ARGS__);                                           \
+    case 3: return FN<E, NBITS, 512, 16, 1>(__VA_ARGS__);                                           \
+    case 4: return FN<E, NBITS, 1024, 16, 0>(__VA_ARGS__);                                          \
+    case 5: return FN<E, NBITS, 1024, 16, 1>(__VA_ARGS__);                                          \
+    case 6: return FN<E, NBITS, 512, 8, 0>(__VA_ARGS__);                                            \
+    case 7: return FN<E, NBITS, 512, 8, 1>(__VA_ARGS__);                                            \
+    case 8: return FN<E, NBITS, 1024, 8, 0>(__VA_ARGS__);                                           \
+    case 9: return FN<E, NBITS, 1024, 8, 1>(__VA_ARGS__);                                           \
+    case 10: return FN<E, NBITS, 256, 32, 0>(__VA_ARGS__);                                          \
+    case 11: return FN<E, NBITS, 256, 32, 1>(__VA_ARGS__);                                          \
+    default: return fail("bad tile variant %d", d->tile_variant);                                   \
+    }
+
+template <typename E, int NBITS>
+int dispatch_scatter(adlhip_device* d, const E* src, E* dst, const uint32_t* table, const uint32_t* totals, size_t n,
+                     const Geometry& g, int start_bit)
+{
+    ADLHIP_DISPATCH_TILE(launch_scatter, E, NBITS, d, src, dst, table, totals, n, g, start_bit)
 }
 
 template <typename E, int NBITS>
 int three_kernel_pass(adlhip_device* d, const E* src, E* dst, void* work, size_t n, int start_bit)
 {
-    using C = adlhip::TileCfg<E, NBITS, kNT, kK>;
-    const Geometry g = geometry(d, n);
+    constexpr int kCountNT = 256;
+    const Geometry g = geometry(d, n, current_tile(d));
     uint32_t* table = reinterpret_cast<uint32_t*>(work);
-    uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + align_up((size_t)256 * g.n_wgs * 4, 256));
-    const uint32_t elems_per_wg = g.tiles_per_wg * kTile;
-    int rc;
-    rc = launch(d, NBITS == 8 ? (sizeof(E) == 4 ? "count_u32_8b" : "count_e64_8b") : (sizeof(E) == 4 ? "count_u32_4b" : "count_e64_4b"), [&] {
-        hipLaunchKernelGGL((adlhip::radix_count_kernel<E, NBITS, kNT>), dim3(g.n_wgs), dim3(kNT), 0, d->stream,
+    uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + table_bytes(d, n, kMinTile));
+    const uint32_t elems_per_wg = g.tiles_per_wg * g.tile;
+    int rc = launch(d, kernel_name<E, NBITS>("count"), [&] {
+        hipLaunchKernelGGL((adlhip::radix_count_kernel<E, NBITS, kCountNT>), dim3(g.n_wgs), dim3(kCountNT), 0, d->stream,
                            src, table, (uint32_t)n, (int)g.n_wgs, start_bit, elems_per_wg);
     });
     if (rc) return rc;
     rc = launch(d, "scan_table", [&] {
-        hipLaunchKernelGGL((adlhip::radix_scan_table_kernel<256>), dim3(C::BINS), dim3(256), 0, d->stream,
-                           table, totals, (int)g.n_wgs);
+        hipLaunchKernelGGL((adlhip::radix_scan_table_kernel<256>), dim3(1 << NBITS), dim3(256), 0, d->stream, table,
+                           totals, (int)g.n_wgs);
     });
     if (rc) return rc;
-    rc = launch(d, NBITS == 8 ? (sizeof(E) == 4 ? "scatter_u32_8b" : "scatter_e64_8b") : (sizeof(E) == 4 ? "scatter_u32_4b" : "scatter_e64_4b"), [&] {
-        hipLaunchKernelGGL((adlhip::radix_scatter_kernel<E, NBITS, kNT, kK>), dim3(g.n_wgs), dim3(kNT),
-                           C::LDS_BYTES, d->stream, src, dst, table, totals, (uint32_t)n, (int)g.n_wgs,
-                           start_bit, g.tiles_per_wg, g.num_tiles);
-    });
-    return rc;
+    return dispatch_scatter<E, NBITS>(d, src, dst, table, totals, n, g, start_bit);
 }
 
 // ---- onesweep --------------------------------------------------------------------------------
 
 // work buffer layout (onesweep):
-//   [ctrl: per pass {ticket u32} padded to 64 B ... 16 passes = 1024 B]
-//   [ghist: 16 passes x 256 u32 global digit bases]
+//   [ctrl: one 64-byte slot per pass holding the tile ticket; 16 passes = 1024 B]
+//   [gbase: 16 passes x 256 u32 global digit bases]
 //   [partial hist: hist_wgs x passes x 256 u32]
 //   [status: passes x num_tiles x 256 u32]
 struct OnesweepLayout {
-    size_t off_ctrl, off_ghist, off_part, off_status, total;
-    uint32_t hist_wgs, num_tiles;
-    int max_passes;
+    size_t off_ctrl, off_gbase, off_part, off_status, total;
+    uint32_t hist_wgs;
 };
 
-OnesweepLayout onesweep_layout(const adlhip_device* d, size_t n, int max_passes)
+uint32_t hist_wgs_for(const adlhip_device* d, size_t n)
+{
+    const uint32_t cap = (uint32_t)d->prop.multiProcessorCount;   // one 1024-thread workgroup per CU
+    uint32_t w = (uint32_t)((n + adlhip::kHistChunk - 1) / adlhip::kHistChunk);
+    if (w > cap) w = cap;
+    return w ? w : 1;
+}
+
+OnesweepLayout onesweep_layout(const adlhip_device* d, size_t n, int max_passes, uint32_t tile)
 {
     OnesweepLayout L;
-    L.max_passes = max_passes;
-    L.num_tiles = (uint32_t)((n + adlhip::kOsTile - 1) / adlhip::kOsTile);
-    if (L.num_tiles == 0) L.num_tiles = 1;
-    const uint32_t cap = (uint32_t)d->prop.multiProcessorCount * 4;
-    L.hist_wgs = std::min<uint32_t>(cap, (uint32_t)((n + adlhip::kHistChunk - 1) / adlhip::kHistChunk));
-    if (L.hist_wgs == 0) L.hist_wgs = 1;
+    uint32_t num_tiles = (uint32_t)((n + tile - 1) / tile);
+    if (num_tiles == 0) num_tiles = 1;
+    L.hist_wgs = hist_wgs_for(d, n);
     L.off_ctrl = 0;
-    L.off_ghist = 1024;
-    L.off_part = L.off_ghist + (size_t)16 * 256 * 4;
+    L.off_gbase = 1024;
+    L.off_part = L.off_gbase + (size_t)16 * 256 * 4;
     L.off_status = align_up(L.off_part + (size_t)L.hist_wgs * max_passes * 256 * 4, 256);
-    L.total = L.off_status + (size_t)max_passes * L.num_tiles * 256 * 4;
+    L.total = L.off_status + (size_t)max_passes * num_tiles * 256 * 4;
     return L;
+}
+
+template <typename E, int NBITS, int NT, int K, int RANK>
+int launch_onesweep(adlhip_device* d, const E* src, E* dst, const uint32_t* gbase, uint32_t* status, uint32_t* ticket,
+                    size_t n, uint32_t num_tiles, int start_bit)
+{
+    using C = adlhip::TileCfg<E, NBITS, NT, K>;
+    auto kern = adlhip::onesweep_pass_kernel<E, NBITS, NT, K, RANK>;
+    if (ensure_lds(kern, C::LDS_BYTES)) return ADLHIP_FAILURE;
+    return launch(d, kernel_name<E, NBITS>("onesweep"), [&] {
+        hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(NT), C::LDS_BYTES, d->stream, src, dst, gbase, status, ticket,
+                           d->d_fault, (uint32_t)n, start_bit, num_tiles);
+    });
+}
+
+template <typename E, int NBITS>
+int dispatch_onesweep(adlhip_device* d, const E* src, E* dst, const uint32_t* gbase, uint32_t* status, uint32_t* ticket,
+                      size_t n, uint32_t num_tiles, int start_bit)
+{
+    ADLHIP_DISPATCH_TILE(launch_onesweep, E, NBITS, d, src, dst, gbase, status, ticket, n, num_tiles, start_bit)
 }
 
 template <typename E>
 int onesweep_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, const std::vector<PassPlan>& plan)
 {
     const int P = (int)plan.size();
-    const OnesweepLayout L = onesweep_layout(d, n, (int)(sizeof(E) == 4 ? 8 : 16));
+    const uint32_t tile = current_tile(d);
+    const uint32_t num_tiles = (uint32_t)((n + tile - 1) / tile);
+    // offsets come from the worst-case layout the caller sized the buffer with
+    const OnesweepLayout L = onesweep_layout(d, n, (int)(sizeof(E) == 4 ? 8 : 16), kMinTile);
     char* wb = reinterpret_cast<char*>(work);
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(wb + L.off_ctrl);
-    uint32_t* ghist = reinterpret_cast<uint32_t*>(wb + L.off_ghist);
+    uint32_t* gbase = reinterpret_cast<uint32_t*>(wb + L.off_gbase);
     uint32_t* part = reinterpret_cast<uint32_t*>(wb + L.off_part);
     uint32_t* status = reinterpret_cast<uint32_t*>(wb + L.off_status);
 
-    // zero tickets + every status word of the passes we run (one memset; status is contiguous)
+    // zero the tickets and every status word of the passes we run (status is contiguous)
     HIPCHK(hipMemsetAsync(ctrl, 0, 1024, d->stream));
-    HIPCHK(hipMemsetAsync(status, 0, (size_t)P * L.num_tiles * 256 * 4, d->stream));
+    HIPCHK(hipMemsetAsync(status, 0, (size_t)P * num_tiles * 256 * 4, d->stream));
 
     adlhip::PassDesc desc;
     desc.num_passes = P;
@@ -290,39 +389,25 @@ int onesweep_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, const
         desc.start_bit[i] = (uint8_t)plan[i].start_bit;
         desc.nbits[i] = (uint8_t)plan[i].nbits;
     }
-    int rc;
     const uint32_t chunk = (uint32_t)align_up((n + L.hist_wgs - 1) / L.hist_wgs, 1024);
-    rc = launch(d, sizeof(E) == 4 ? "os_hist_u32" : "os_hist_e64", [&] {
-        hipLaunchKernelGGL((adlhip::onesweep_hist_kernel<E>), dim3(L.hist_wgs), dim3(adlhip::kHistNT), 0, d->stream,
-                           data, part, (uint32_t)n, chunk, desc);
+    int rc = launch(d, sizeof(E) == 4 ? "os_hist_u32" : "os_hist_e64", [&] {
+        hipLaunchKernelGGL((adlhip::onesweep_hist_kernel<E>), dim3(L.hist_wgs), dim3(adlhip::kHistNT), 0, d->stream, data,
+                           part, (uint32_t)n, chunk, desc);
     });
     if (rc) return rc;
     rc = launch(d, "os_hist_reduce", [&] {
-        hipLaunchKernelGGL(adlhip::onesweep_hist_reduce_kernel, dim3(P), dim3(256), 0, d->stream,
-                           part, ghist, L.hist_wgs, P);
+        hipLaunchKernelGGL(adlhip::onesweep_hist_reduce_kernel, dim3(P), dim3(1024), 0, d->stream, part, gbase,
+                           L.hist_wgs, P);
     });
     if (rc) return rc;
 
     E* src = data;
     E* dst = tmp;
     for (int i = 0; i < P; ++i) {
-        uint32_t* st = status + (size_t)i * L.num_tiles * 256;
-        const int sb = plan[i].start_bit;
-        if (plan[i].nbits == 8) {
-            using C = adlhip::TileCfg<E, 8, adlhip::kOsNT, adlhip::kOsK>;
-            rc = launch(d, sizeof(E) == 4 ? "onesweep_u32_8b" : "onesweep_e64_8b", [&] {
-                hipLaunchKernelGGL((adlhip::onesweep_pass_kernel<E, 8, adlhip::kOsNT, adlhip::kOsK>),
-                                   dim3(L.num_tiles), dim3(adlhip::kOsNT), C::LDS_BYTES, d->stream, src, dst,
-                                   ghist + i * 256, st, ctrl + i * 16, d->d_fault, (uint32_t)n, sb, L.num_tiles);
-            });
-        } else {
-            using C = adlhip::TileCfg<E, 4, adlhip::kOsNT, adlhip::kOsK>;
-            rc = launch(d, sizeof(E) == 4 ? "onesweep_u32_4b" : "onesweep_e64_4b", [&] {
-                hipLaunchKernelGGL((adlhip::onesweep_pass_kernel<E, 4, adlhip::kOsNT, adlhip::kOsK>),
-                                   dim3(L.num_tiles), dim3(adlhip::kOsNT), C::LDS_BYTES, d->stream, src, dst,
-                                   ghist + i * 256, st, ctrl + i * 16, d->d_fault, (uint32_t)n, sb, L.num_tiles);
-            });
-        }
+        uint32_t* st = status + (size_t)i * num_tiles * 256;
+        rc = (plan[i].nbits == 8)
+                 ? dispatch_onesweep<E, 8>(d, src, dst, gbase + i * 256, st, ctrl + i * 16, n, num_tiles, plan[i].start_bit)
+                 : dispatch_onesweep<E, 4>(d, src, dst, gbase + i * 256, st, ctrl + i * 16, n, num_tiles, plan[i].start_bit);
         if (rc) return rc;
         std::swap(src, dst);
     }
@@ -349,7 +434,7 @@ int three_kernel_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, c
 size_t sort_work_bytes(const adlhip_device* d, int elem_kind, size_t n)
 {
     const size_t a = work_bytes_three_kernel(d, n);
-    const size_t b = onesweep_layout(d, n, elem_kind == ADLHIP_ELEM_U64 ? 16 : 8).total;
+    const size_t b = onesweep_layout(d, n, elem_kind == ADLHIP_ELEM_U32 ? 8 : 16, kMinTile).total;   // as onesweep_sort<E>()
     return std::max(a, b);
 }
 
@@ -423,7 +508,21 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         delete d;
         return fail("cannot allocate the fault word");
     }
-    if (const char* a = getenv("ADLHIP_SORT_ALGO")) d->sort_algo = atoi(a);
+    {   // self-test: are returning DS atomics lane-ordered on this device?  (enables "sort.rank" = 1)
+        uint32_t mism = 1;
+        bool ok = hipMemsetAsync(d->d_fault + 8, 0, 4, d->stream) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(adlhip::lds_order_selftest_kernel, dim3(64), dim3(256), 0, d->stream, d->d_fault + 8);
+            ok = hipGetLastError() == hipSuccess &&
+                 hipMemcpyAsync(&mism, d->d_fault + 8, 4, hipMemcpyDeviceToHost, d->stream) == hipSuccess &&
+                 hipStreamSynchronize(d->stream) == hipSuccess;
+        }
+        d->lds_ordered = (ok && mism == 0) ? 1 : 0;
+        d->rank_mode = d->lds_ordered;
+    }
+    if (const char* a = getenv("ADLHIP_SORT_ALGO")) d->sort_algo = atoi(a) ? 1 : 0;
+    if (const char* t = getenv("ADLHIP_SORT_TILE")) { int v = atoi(t); if (v >= 0 && v < kNumVariants) d->tile_variant = v; }
+    if (const char* r = getenv("ADLHIP_SORT_RANK")) d->rank_mode = (atoi(r) && d->lds_ordered) ? 1 : 0;
     if (const char* b = getenv("ADLHIP_DIGIT_BITS")) d->digit_bits = (atoi(b) == 4) ? 4 : 8;
     *out = d;
     return ADLHIP_SUCCESS;
@@ -707,8 +806,7 @@ int adlhip_partition_msb_u32(adlhip_device* d, const uint32_t* in, uint32_t* out
     // whole top byte refines buckets without mixing them), then fold the 256 digit totals into buckets
     int rc = three_kernel_pass<uint32_t, 8>(d, in, out, work, n, 24);
     if (rc) return rc;
-    const Geometry g = geometry(d, n);
-    uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + align_up((size_t)256 * g.n_wgs * 4, 256));
+    uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + table_bytes(d, n, kMinTile));
     return launch(d, "fold_buckets", [&] {
         hipLaunchKernelGGL(adlhip::fold_buckets_kernel, dim3(1), dim3(256), 0, d->stream, (const uint32_t*)totals, counts, num_buckets);
     });
@@ -740,6 +838,13 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
     } else if (!strcmp(name, "sort.digit_bits")) {
         if (value != 4 && value != 8) return fail("sort.digit_bits must be 4 or 8");
         d->digit_bits = value;
+    } else if (!strcmp(name, "sort.tile")) {
+        if (value < 0 || value >= kNumVariants) return fail("sort.tile must be in [0,%d)", kNumVariants);
+        d->tile_variant = value;
+    } else if (!strcmp(name, "sort.rank")) {
+        if (value != 0 && value != 1) return fail("sort.rank must be 0 or 1");
+        if (value == 1 && !d->lds_ordered) return fail("sort.rank = 1 needs lane-ordered DS atomics; the device self-test failed");
+        d->rank_mode = value;
     } else if (!strcmp(name, "profile")) {
         if (bind(d)) return ADLHIP_FAILURE;
         if (!value && fold_profile(d)) return ADLHIP_FAILURE;
@@ -755,6 +860,9 @@ int adlhip_get_param(adlhip_device* d, const char* name, int* value)
     if (!d || !name || !value) return fail("null argument");
     if (!strcmp(name, "sort.algo")) *value = d->sort_algo;
     else if (!strcmp(name, "sort.digit_bits")) *value = d->digit_bits;
+    else if (!strcmp(name, "sort.tile")) *value = d->tile_variant;
+    else if (!strcmp(name, "sort.rank")) *value = d->rank_mode;
+    else if (!strcmp(name, "sort.lds_ordered")) *value = d->lds_ordered;
     else if (!strcmp(name, "profile")) *value = d->profile;
     else return fail("unknown parameter '%s'", name);
     return ADLHIP_SUCCESS;

@@ -30,7 +30,7 @@ constexpr int kOsNT = 256;
 constexpr int kOsK = 16;
 constexpr uint32_t kOsTile = kOsNT * kOsK;
 
-constexpr int kHistNT = 512;
+constexpr int kHistNT = 1024;
 constexpr uint32_t kHistChunk = 64 * 1024;   // minimum elements per histogram workgroup
 
 struct PassDesc {
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(1024) void onesweep_hist_reduce_kernel(const uint32
     const int d = tid & 255;
     const int g = tid >> 8;
     uint32_t s = 0u;
+#pragma unroll 8
     for (uint32_t wg = (uint32_t)g; wg < n_wgs; wg += 4u) s += partial[((size_t)wg * P + p) * 256 + d];
     red[g][d] = s;
     __syncthreads();
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(1024) void onesweep_hist_reduce_kernel(const uint32
 }
 
 // One tile per workgroup; ticket-ordered tile ids; decoupled look-back per digit.
-template <typename E, int NBITS, int NT, int K>
+template <typename E, int NBITS, int NT, int K, int RANK>
 __global__ __launch_bounds__(NT) void onesweep_pass_kernel(const E* __restrict__ src, E* __restrict__ dst,
                                                            const uint32_t* __restrict__ gbase,
                                                            uint32_t* status, uint32_t* ticket, uint32_t* fault,
@@ -136,8 +137,8 @@ __global__ __launch_bounds__(NT) void onesweep_pass_kernel(const E* __restrict__
     const uint32_t left = n - tile_base;
     const uint32_t valid = left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE;
 
-    sort_scatter_tile<E, NBITS, NT, K>(
-        src, dst, tile_base, valid, start_bit, smem, [&](int b, uint32_t cnt) -> uint32_t {
+    sort_scatter_tile<E, NBITS, NT, K, RANK>(
+        src, dst, tile_base, valid, n, start_bit, smem, [&](int b, uint32_t cnt) -> uint32_t {
             uint32_t* mine = status + (size_t)tile * BINS + b;
             uint32_t excl = 0u;
             if (tile == 0u) {

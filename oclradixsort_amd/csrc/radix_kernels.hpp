@@ -132,10 +132,10 @@ struct TileCfg {
 // `valid` < TILE only for the globally last tile; the missing slots are padded with all-ones keys,
 // which rank after every real element (max digit, highest indices, stable) and are never stored
 // -- the reference's key-value kernel pads the same way (RadixSortKeyValueKernels.cl:554-563).
-template <typename E, int NBITS, int NT, int K, typename BinOffsetFn>
+template <typename E, int NBITS, int NT, int K, int RANK, typename BinOffsetFn>
 __device__ __forceinline__ void sort_scatter_tile(const E* __restrict__ src, E* __restrict__ dst,
-                                                  uint32_t tile_base, uint32_t valid, int start_bit,
-                                                  unsigned char* smem, BinOffsetFn&& bin_offset)
+                                                  uint32_t tile_base, uint32_t valid, uint32_t n_total,
+                                                  int start_bit, unsigned char* smem, BinOffsetFn&& bin_offset)
 {
     using C = TileCfg<E, NBITS, NT, K>;
     constexpr int BINS = C::BINS;
@@ -170,16 +170,28 @@ __device__ __forceinline__ void sort_scatter_tile(const E* __restrict__ src, E* 
 
     // rank within the wave
     uint32_t rnk[K];
+    if constexpr (RANK == 1) {
+        // gfx950: a returning DS atomic issued by one wave-instruction resolves colliding lanes in
+        // ascending lane order, and DS ops of a wave execute in issue order -- so the returned value
+        // IS the stable rank among the wave's elements of this digit seen so far.  Verified at device
+        // creation by lds_order_selftest_kernel; if that ever fails the ballot path below is used.
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const uint32_t d = digit_of<NBITS>(e[j], start_bit);
-        const uint64_t m = match_digit<NBITS>(d);
-        const uint32_t below = mbcnt64(m);
-        const uint32_t cnt = (uint32_t)__popcll(m);
-        const uint32_t old = __hip_atomic_load(&my_wcnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (below == 0u)
-            __hip_atomic_fetch_add(&my_wcnt[d], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        rnk[j] = old + below;
+        for (int j = 0; j < K; ++j) {
+            const uint32_t d = digit_of<NBITS>(e[j], start_bit);
+            rnk[j] = __hip_atomic_fetch_add(&my_wcnt[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t d = digit_of<NBITS>(e[j], start_bit);
+            const uint64_t m = match_digit<NBITS>(d);
+            const uint32_t below = mbcnt64(m);
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            const uint32_t old = __hip_atomic_load(&my_wcnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (below == 0u)
+                __hip_atomic_fetch_add(&my_wcnt[d], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            rnk[j] = old + below;
+        }
     }
     __syncthreads();
 
@@ -221,7 +233,9 @@ __device__ __forceinline__ void sort_scatter_tile(const E* __restrict__ src, E* 
         if (p < valid) {
             const E v = s_elems[p];
             const uint32_t d = digit_of<NBITS>(v, start_bit);
-            dst[(size_t)(uint32_t)(s_goff[d] + p)] = v;
+            const uint32_t g = s_goff[d] + p;
+            if (g < n_total) dst[(size_t)g] = v;   // always true for a sound offset; keeps a faulted
+                                                   // look-back (garbage offset) from writing out of bounds
         }
     }
     __syncthreads();   // LDS is reused by the next tile
@@ -316,7 +330,7 @@ __global__ __launch_bounds__(NT) void radix_scan_table_kernel(uint32_t* __restri
 
 // Stable local sort + scatter of the workgroup's run of tiles, carrying per-digit offsets from tile
 // to tile (RadixSort32Kernels.cl:493-631 behaviour).
-template <typename E, int NBITS, int NT, int K>
+template <typename E, int NBITS, int NT, int K, int RANK>
 __global__ __launch_bounds__(NT) void radix_scatter_kernel(const E* __restrict__ src, E* __restrict__ dst,
                                                            const uint32_t* __restrict__ table,
                                                            const uint32_t* __restrict__ totals, uint32_t n,
@@ -340,7 +354,7 @@ __global__ __launch_bounds__(NT) void radix_scatter_kernel(const E* __restrict__
         const uint32_t tile_base = t * (uint32_t)C::TILE;
         const uint32_t left = n - tile_base;
         const uint32_t valid = left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE;
-        sort_scatter_tile<E, NBITS, NT, K>(src, dst, tile_base, valid, start_bit, smem,
+        sort_scatter_tile<E, NBITS, NT, K, RANK>(src, dst, tile_base, valid, n, start_bit, smem,
                                            [&](int /*b*/, uint32_t cnt) {
                                                const uint32_t g = carry;
                                                carry += cnt;
@@ -505,6 +519,36 @@ __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ ds
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[i] = pattern;
+}
+
+// Device self-test for the RANK == 1 path: do returning DS atomics of one wave-instruction resolve
+// colliding lanes in ascending lane order, and do successive instructions of a wave apply in order?
+// Compares ds_add_rtn ranks with ballot/mbcnt ranks over pseudo-random digits for 1, 2, 16 and 256
+// bins; *mismatches stays 0 iff they agree everywhere.
+__global__ __launch_bounds__(256) void lds_order_selftest_kernel(uint32_t* __restrict__ mismatches)
+{
+    __shared__ uint32_t c_atomic[4][256];
+    __shared__ uint32_t c_ballot[4][256];
+    const int lane = lane_id();
+    const int w = (int)(threadIdx.x >> 6);
+    uint32_t bad = 0u;
+    for (int lg = 0; lg <= 8; lg += (lg < 1 ? 1 : (lg < 4 ? 3 : 4))) {   // bins = 1, 2, 16, 256
+        const uint32_t bins = 1u << lg;
+        for (int b = lane; b < 256; b += 64) { c_atomic[w][b] = 0u; c_ballot[w][b] = 0u; }
+        for (int j = 0; j < 16; ++j) {
+            uint32_t h = (blockIdx.x * 256u + threadIdx.x) * 16u + (uint32_t)j + bins * 0x9E3779B9u;
+            h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+            const uint32_t d = h & (bins - 1u);
+            const uint32_t got = __hip_atomic_fetch_add(&c_atomic[w][d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint64_t m = match_digit<8>(d);
+            const uint32_t below = mbcnt64(m);
+            const uint32_t old = __hip_atomic_load(&c_ballot[w][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (below == 0u)
+                __hip_atomic_fetch_add(&c_ballot[w][d], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            bad += (got != old + below) ? 1u : 0u;
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
 }
 
 // Synthetic inputs, reproducible by index (same function as the oracle's generator).

@@ -17,8 +17,12 @@ from oclradixsort_amd import AdlHipError, Buffer, DeviceUtils, Pprims, Stopwatch
 
 pytestmark = pytest.mark.gpu
 
-ALGOS = [(0, 8), (0, 4), (1, 8), (1, 4)]   # (sort.algo, sort.digit_bits)
-ALGO_IDS = ["onesweep8", "onesweep4", "threekernel8", "threekernel4"]
+# (sort.algo, sort.digit_bits, sort.tile, sort.rank)
+ALGOS = [(0, 8, 0, 1), (0, 4, 0, 1), (1, 8, 0, 1), (1, 4, 0, 1), (0, 8, 0, 0), (1, 8, 0, 0), (0, 8, 2, 1), (1, 8, 1, 1),
+         (0, 8, 3, 1), (1, 8, 4, 0), (0, 8, 5, 1)]
+ALGO_IDS = ["onesweep8", "onesweep4", "threekernel8", "threekernel4", "onesweep8-ballot", "threekernel8-ballot",
+            "onesweep8-1024x16", "threekernel8-512x16", "onesweep8-512x8", "threekernel8-1024x8-ballot",
+            "onesweep8-256x32"]
 
 
 @pytest.fixture(scope="module")
@@ -30,8 +34,7 @@ def dev():
 
 @pytest.fixture()
 def pp(dev):
-    dev.setParam("sort.algo", 0)
-    dev.setParam("sort.digit_bits", 8)
+    set_algo(dev, (0, 8, 0))
     p = Pprims()
     yield p
     p.close()
@@ -40,6 +43,8 @@ def pp(dev):
 def set_algo(dev, algo):
     dev.setParam("sort.algo", algo[0])
     dev.setParam("sort.digit_bits", algo[1])
+    dev.setParam("sort.tile", algo[2] if len(algo) > 2 else 0)
+    dev.setParam("sort.rank", algo[3] if len(algo) > 3 else dev.getParam("sort.lds_ordered"))
 
 
 def gpu_sort_u32(dev, p, keys, bits=32):
@@ -86,6 +91,7 @@ def gpu_scan(dev, p, vals, want_total=False):
 # ---------------------------------------------------------------------------------------------
 def test_device_is_mi355x(dev):
     assert dev.info.arch.decode().startswith("gfx950")
+    assert dev.getParam("sort.lds_ordered") == 1     # the fast ranking path is the one under test
     assert dev.info.wavefront_size == 64
     assert DeviceUtils.getNCUs(dev) >= 1
     assert DeviceUtils.getNDevices() >= 1
