@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libadlhip.so")
+# ADLHIP_LIB: explicit path to another build of the same ABI (e.g. the phase-stamp diagnostic build)
+LIB_PATH = os.environ.get("ADLHIP_LIB") or os.path.join(_HERE, "lib", "libadlhip.so")
 
 c_void_pp = ctypes.POINTER(ctypes.c_void_p)
 c_size_p = ctypes.POINTER(ctypes.c_size_t)

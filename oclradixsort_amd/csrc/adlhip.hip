@@ -72,6 +72,7 @@ struct adlhip_device {
     int tile_variant = 0;     // index into kVariants
     int rank_mode = 1;        // 1 = lane-ordered DS atomic ranking (needs lds_ordered), 0 = ballot match
     int lds_ordered = 0;      // result of the device self-test at creation
+    int wgs_per_cu = 0;       // persistent kernels: cap on resident workgroups per CU (0 = occupancy limit)
     // profiling
     std::vector<PendingProf> pending;
     std::vector<hipEvent_t> event_pool;
@@ -172,7 +173,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct TileVariant {
     int nt, k;
 };
-constexpr TileVariant kVariants[] = {{256, 16}, {512, 16}, {1024, 16}, {512, 8}, {1024, 8}, {256, 32}};
+constexpr TileVariant kVariants[] = {{256, 16}, {512, 16}, {1024, 16}, {512, 8}, {1024, 8}, {256, 32}, {512, 32}};
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr uint32_t kMinTile = 4096;
 constexpr int kWgsPerCu = 8;   // three-kernel pass: workgroups per CU that each own a run of tiles
@@ -280,6 +281,8 @@ int launch_scatter(adlhip_device* d, const E* src, E* dst, const uint32_t* table
     case 9: return FN<E, NBITS, 1024, 8, 1>(__VA_ARGS__);                                           \
     case 10: return FN<E, NBITS, 256, 32, 0>(__VA_ARGS__);                                          \
     case 11: return FN<E, NBITS, 256, 32, 1>(__VA_ARGS__);                                          \
+    case 12: return FN<E, NBITS, 512, 32, 0>(__VA_ARGS__);                                          \
+    case 13: return FN<E, NBITS, 512, 32, 1>(__VA_ARGS__);                                          \
     default: return fail("bad tile variant %d", d->tile_variant);                                   \
     }
 
@@ -331,6 +334,9 @@ uint32_t hist_wgs_for(const adlhip_device* d, size_t n)
     return w ? w : 1;
 }
 
+// status rows of one pass: one per tile + one per look-back block of tiles
+size_t status_rows(uint32_t num_tiles) { return (size_t)num_tiles + num_tiles / adlhip::kLookbackBlock + 1; }
+
 OnesweepLayout onesweep_layout(const adlhip_device* d, size_t n, int max_passes, uint32_t tile)
 {
     OnesweepLayout L;
@@ -341,7 +347,7 @@ OnesweepLayout onesweep_layout(const adlhip_device* d, size_t n, int max_passes,
     L.off_gbase = 1024;
     L.off_part = L.off_gbase + (size_t)16 * 256 * 4;
     L.off_status = align_up(L.off_part + (size_t)L.hist_wgs * max_passes * 256 * 4, 256);
-    L.total = L.off_status + (size_t)max_passes * num_tiles * 256 * 4;
+    L.total = L.off_status + (size_t)max_passes * status_rows(num_tiles) * 256 * 4;
     return L;
 }
 
@@ -350,11 +356,40 @@ int launch_onesweep(adlhip_device* d, const E* src, E* dst, const uint32_t* gbas
                     size_t n, uint32_t num_tiles, int start_bit)
 {
     using C = adlhip::TileCfg<E, NBITS, NT, K>;
-    auto kern = adlhip::onesweep_pass_kernel<E, NBITS, NT, K, RANK>;
+    const uint32_t status_bytes = (uint32_t)(status_rows(num_tiles) * C::BINS * 4u);
+    if (d->sort_algo == 2) {   // same tile body, one tile per workgroup (the hardware dispatcher overlaps tiles)
+        auto kern1 = adlhip::onesweep_persistent_kernel<E, NBITS, NT, K, RANK, false>;
+        if (ensure_lds(kern1, C::LDS_BYTES)) return ADLHIP_FAILURE;
+        return launch(d, kernel_name<E, NBITS>("onesweep1"), [&] {
+            hipLaunchKernelGGL(kern1, dim3(num_tiles), dim3(NT), C::LDS_BYTES, d->stream, src, dst, gbase, status,
+                               status_bytes, ticket, d->d_fault, (uint32_t)n, start_bit, num_tiles);
+        });
+    }
+    if (d->sort_algo == 3) {   // first version: thread-per-digit look-back before the LDS scatter
+        auto kern0 = adlhip::onesweep_pass_kernel<E, NBITS, NT, K, RANK>;
+        if (ensure_lds(kern0, C::LDS_BYTES)) return ADLHIP_FAILURE;
+        return launch(d, kernel_name<E, NBITS>("onesweep0"), [&] {
+            hipLaunchKernelGGL(kern0, dim3(num_tiles), dim3(NT), C::LDS_BYTES, d->stream, src, dst, gbase, status, ticket,
+                               d->d_fault, (uint32_t)n, start_bit, num_tiles);
+        });
+    }
+    auto kern = adlhip::onesweep_persistent_kernel<E, NBITS, NT, K, RANK, true>;
     if (ensure_lds(kern, C::LDS_BYTES)) return ADLHIP_FAILURE;
+    // persistent grid: as many workgroups as can be resident (advisory -- tiles come from a ticket, so
+    // correctness does not depend on residency), never more than there are tiles
+    static int occ = 0;   // per instantiation
+    if (occ == 0) {
+        int o = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kern, NT, C::LDS_BYTES) != hipSuccess || o < 1) o = 1;
+        occ = o;
+    }
+    int per_cu = occ;
+    if (d->wgs_per_cu > 0 && d->wgs_per_cu < per_cu) per_cu = d->wgs_per_cu;
+    uint32_t grid = (uint32_t)d->prop.multiProcessorCount * (uint32_t)per_cu;
+    if (grid > num_tiles) grid = num_tiles;
     return launch(d, kernel_name<E, NBITS>("onesweep"), [&] {
-        hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(NT), C::LDS_BYTES, d->stream, src, dst, gbase, status, ticket,
-                           d->d_fault, (uint32_t)n, start_bit, num_tiles);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), C::LDS_BYTES, d->stream, src, dst, gbase, status, status_bytes,
+                           ticket, d->d_fault, (uint32_t)n, start_bit, num_tiles);
     });
 }
 
@@ -381,7 +416,7 @@ int onesweep_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, const
 
     // zero the tickets and every status word of the passes we run (status is contiguous)
     HIPCHK(hipMemsetAsync(ctrl, 0, 1024, d->stream));
-    HIPCHK(hipMemsetAsync(status, 0, (size_t)P * num_tiles * 256 * 4, d->stream));
+    HIPCHK(hipMemsetAsync(status, 0, (size_t)P * status_rows(num_tiles) * 256 * 4, d->stream));
 
     adlhip::PassDesc desc;
     desc.num_passes = P;
@@ -404,7 +439,7 @@ int onesweep_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, const
     E* src = data;
     E* dst = tmp;
     for (int i = 0; i < P; ++i) {
-        uint32_t* st = status + (size_t)i * num_tiles * 256;
+        uint32_t* st = status + (size_t)i * status_rows(num_tiles) * 256;
         rc = (plan[i].nbits == 8)
                  ? dispatch_onesweep<E, 8>(d, src, dst, gbase + i * 256, st, ctrl + i * 16, n, num_tiles, plan[i].start_bit)
                  : dispatch_onesweep<E, 4>(d, src, dst, gbase + i * 256, st, ctrl + i * 16, n, num_tiles, plan[i].start_bit);
@@ -520,7 +555,7 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         d->lds_ordered = (ok && mism == 0) ? 1 : 0;
         d->rank_mode = d->lds_ordered;
     }
-    if (const char* a = getenv("ADLHIP_SORT_ALGO")) d->sort_algo = atoi(a) ? 1 : 0;
+    if (const char* a = getenv("ADLHIP_SORT_ALGO")) { int v = atoi(a); if (v >= 0 && v <= 3) d->sort_algo = v; }
     if (const char* t = getenv("ADLHIP_SORT_TILE")) { int v = atoi(t); if (v >= 0 && v < kNumVariants) d->tile_variant = v; }
     if (const char* r = getenv("ADLHIP_SORT_RANK")) d->rank_mode = (atoi(r) && d->lds_ordered) ? 1 : 0;
     if (const char* b = getenv("ADLHIP_DIGIT_BITS")) d->digit_bits = (atoi(b) == 4) ? 4 : 8;
@@ -833,7 +868,7 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
 {
     if (!d || !name) return fail("null argument");
     if (!strcmp(name, "sort.algo")) {
-        if (value != 0 && value != 1) return fail("sort.algo must be 0 or 1");
+        if (value < 0 || value > 3) return fail("sort.algo must be in [0,3]");
         d->sort_algo = value;
     } else if (!strcmp(name, "sort.digit_bits")) {
         if (value != 4 && value != 8) return fail("sort.digit_bits must be 4 or 8");
@@ -841,6 +876,9 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
     } else if (!strcmp(name, "sort.tile")) {
         if (value < 0 || value >= kNumVariants) return fail("sort.tile must be in [0,%d)", kNumVariants);
         d->tile_variant = value;
+    } else if (!strcmp(name, "sort.wgs_per_cu")) {
+        if (value < 0 || value > 16) return fail("sort.wgs_per_cu must be in [0,16]");
+        d->wgs_per_cu = value;
     } else if (!strcmp(name, "sort.rank")) {
         if (value != 0 && value != 1) return fail("sort.rank must be 0 or 1");
         if (value == 1 && !d->lds_ordered) return fail("sort.rank = 1 needs lane-ordered DS atomics; the device self-test failed");
@@ -862,6 +900,7 @@ int adlhip_get_param(adlhip_device* d, const char* name, int* value)
     else if (!strcmp(name, "sort.digit_bits")) *value = d->digit_bits;
     else if (!strcmp(name, "sort.tile")) *value = d->tile_variant;
     else if (!strcmp(name, "sort.rank")) *value = d->rank_mode;
+    else if (!strcmp(name, "sort.wgs_per_cu")) *value = d->wgs_per_cu;
     else if (!strcmp(name, "sort.lds_ordered")) *value = d->lds_ordered;
     else if (!strcmp(name, "profile")) *value = d->profile;
     else return fail("unknown parameter '%s'", name);
@@ -936,6 +975,16 @@ int adlhip_profile_get(adlhip_device* d, int i, char name_out[64], uint64_t* lau
     if (total_ms) *total_ms = e.total_ms;
     return ADLHIP_SUCCESS;
 }
+
+#ifdef ADLHIP_STAMPS
+// Diagnostic build only: point the phase-stamp side buffer at caller-provided device memory ([tiles][16] u64).
+int adlhip_debug_set_stamp_buffer(adlhip_device* d, void* dptr)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(adlhip::g_stamp_buf), &dptr, sizeof(void*)));
+    return ADLHIP_SUCCESS;
+}
+#endif
 
 // ---- probes ---------------------------------------------------------------------------------------
 

@@ -25,14 +25,24 @@ namespace adlhip {
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// DPP move with zero fill: lanes whose source is outside the row / masked off receive 0.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp_mov0(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+// 64-lane inclusive scan in six v_add_u32_dpp (no LDS traffic): row_shr 1/2/4/8 scans each row of 16,
+// row_bcast:15 carries row 0 -> 1 and 2 -> 3, row_bcast:31 carries the first half into rows 2 and 3.
+// All 64 lanes must be active.
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 {
-    const int lane = lane_id();
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
+    v += dpp_mov0<0x111, 0xf, 0xf>(v);   // row_shr:1
+    v += dpp_mov0<0x112, 0xf, 0xf>(v);   // row_shr:2
+    v += dpp_mov0<0x114, 0xf, 0xf>(v);   // row_shr:4
+    v += dpp_mov0<0x118, 0xf, 0xf>(v);   // row_shr:8
+    v += dpp_mov0<0x142, 0xa, 0xf>(v);   // row_bcast:15 -> rows 1, 3
+    v += dpp_mov0<0x143, 0xc, 0xf>(v);   // row_bcast:31 -> rows 2, 3
     return v;
 }
 
@@ -96,6 +106,25 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
 }
 
 // ------------------------------------------------------------------------------------------
+// Diagnostic build only (-DADLHIP_STAMPS, never in the shipped library): wave 0 / lane 0 of every
+// tile records s_memtime at phase boundaries into a side buffer that no kernel reads.
+// ------------------------------------------------------------------------------------------
+#ifdef ADLHIP_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;   // [tiles][16]
+__device__ __forceinline__ void stamp_at(uint32_t tile, int slot)
+{
+    if (threadIdx.x == 0 && g_stamp_buf) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        g_stamp_buf[(size_t)tile * 16 + slot] = t;
+    }
+}
+#define ADLHIP_STAMP(tile, slot) stamp_at(tile, slot)
+#else
+#define ADLHIP_STAMP(tile, slot) ((void)0)
+#endif
+
+// ------------------------------------------------------------------------------------------
 // Tile geometry shared by the scatter kernels
 // ------------------------------------------------------------------------------------------
 template <typename E, int NBITS, int NT, int K>
@@ -113,6 +142,38 @@ struct TileCfg {
     static constexpr size_t OFF_MISC = OFF_WSUM + 16 * ((NW + 1 + 3) / 4) * 4;
     static constexpr size_t LDS_BYTES = OFF_MISC + 64;
 };
+
+// Stable rank of each of a lane's K elements among the wave's elements with the same digit, in
+// (item, lane) order; my_wcnt[digit] ends up holding the wave's count per digit (it must be zero on
+// entry).  RANK == 1: one returning DS atomic per element -- on gfx950 a returning DS atomic issued
+// by one wave-instruction resolves colliding lanes in ascending lane order and the DS ops of a wave
+// execute in issue order, so the returned value IS the stable rank (checked at device creation by
+// lds_order_selftest_kernel; if that ever fails the host selects RANK == 0).  RANK == 0: 64-lane
+// ballot match: peers = lanes with my digit, rank = wave's running count (read by all peers, bumped by
+// the lowest peer) + number of lower peers.
+template <typename E, int NBITS, int K, int RANK>
+__device__ __forceinline__ void rank_in_wave(const E (&e)[K], uint32_t (&rnk)[K], uint32_t* my_wcnt, int start_bit)
+{
+    if constexpr (RANK == 1) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t d = digit_of<NBITS>(e[j], start_bit);
+            rnk[j] = __hip_atomic_fetch_add(&my_wcnt[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t d = digit_of<NBITS>(e[j], start_bit);
+            const uint64_t m = match_digit<NBITS>(d);
+            const uint32_t below = mbcnt64(m);
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            const uint32_t old = __hip_atomic_load(&my_wcnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (below == 0u)
+                __hip_atomic_fetch_add(&my_wcnt[d], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            rnk[j] = old + below;
+        }
+    }
+}
 
 // Stable in-tile ranking + local scatter + coalesced write-out of ONE tile.
 //
@@ -150,6 +211,9 @@ __device__ __forceinline__ void sort_scatter_tile(const E* __restrict__ src, E* 
     const int w = tid >> 6;
     uint32_t* my_wcnt = s_wcnt + w * BINS;
 
+    const uint32_t stamp_tile = tile_base / (uint32_t)C::TILE;
+    (void)stamp_tile;
+    ADLHIP_STAMP(stamp_tile, 0);
     // zero this wave's digit counters (wave-private row: no barrier needed before its own DS ops)
 #pragma unroll
     for (int b = lane; b < BINS; b += 64) my_wcnt[b] = 0u;
@@ -168,32 +232,22 @@ __device__ __forceinline__ void sort_scatter_tile(const E* __restrict__ src, E* 
         }
     }
 
+#ifdef ADLHIP_STAMPS
+    {   // force the loads to land so the stamp separates load latency from ranking
+        E acc = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc ^= e[j];
+        if (acc == (E)0x1234567) my_wcnt[0] = 1u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#endif
+    ADLHIP_STAMP(stamp_tile, 1);
     // rank within the wave
     uint32_t rnk[K];
-    if constexpr (RANK == 1) {
-        // gfx950: a returning DS atomic issued by one wave-instruction resolves colliding lanes in
-        // ascending lane order, and DS ops of a wave execute in issue order -- so the returned value
-        // IS the stable rank among the wave's elements of this digit seen so far.  Verified at device
-        // creation by lds_order_selftest_kernel; if that ever fails the ballot path below is used.
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const uint32_t d = digit_of<NBITS>(e[j], start_bit);
-            rnk[j] = __hip_atomic_fetch_add(&my_wcnt[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const uint32_t d = digit_of<NBITS>(e[j], start_bit);
-            const uint64_t m = match_digit<NBITS>(d);
-            const uint32_t below = mbcnt64(m);
-            const uint32_t cnt = (uint32_t)__popcll(m);
-            const uint32_t old = __hip_atomic_load(&my_wcnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (below == 0u)
-                __hip_atomic_fetch_add(&my_wcnt[d], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            rnk[j] = old + below;
-        }
-    }
+    rank_in_wave<E, NBITS, K, RANK>(e, rnk, my_wcnt, start_bit);
+    ADLHIP_STAMP(stamp_tile, 2);
     __syncthreads();
+    ADLHIP_STAMP(stamp_tile, 3);
 
     // thread b: wave offsets for digit b, tile total, tile offset, global run start
     uint32_t cnt_b = 0u;
@@ -213,10 +267,13 @@ __device__ __forceinline__ void sort_scatter_tile(const E* __restrict__ src, E* 
             s_wcnt[i * BINS + tid] = run;   // tile position of (wave i, digit b)'s first element
             run += wc[i];
         }
+        ADLHIP_STAMP(stamp_tile, 4);
         const uint32_t gstart = bin_offset(tid, cnt_b);
+        ADLHIP_STAMP(stamp_tile, 5);
         s_goff[tid] = gstart - toff;        // dst index = goff[d] + tile position (mod 2^32)
     }
     __syncthreads();
+    ADLHIP_STAMP(stamp_tile, 6);
 
     // local scatter into tile-sorted order
 #pragma unroll
@@ -224,7 +281,9 @@ __device__ __forceinline__ void sort_scatter_tile(const E* __restrict__ src, E* 
         const uint32_t d = digit_of<NBITS>(e[j], start_bit);
         s_elems[my_wcnt[d] + rnk[j]] = e[j];
     }
+    ADLHIP_STAMP(stamp_tile, 7);
     __syncthreads();
+    ADLHIP_STAMP(stamp_tile, 8);
 
     // write-out: consecutive threads -> consecutive tile positions -> contiguous runs per digit
 #pragma unroll
@@ -238,7 +297,9 @@ __device__ __forceinline__ void sort_scatter_tile(const E* __restrict__ src, E* 
                                                    // look-back (garbage offset) from writing out of bounds
         }
     }
+    ADLHIP_STAMP(stamp_tile, 9);
     __syncthreads();   // LDS is reused by the next tile
+    ADLHIP_STAMP(stamp_tile, 10);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,3 @@
+#!/bin/bash
+export TMPDIR=/tmp; mkdir -p gpurun_out
+timeout 1200 python tools/sweep.py --steps 5 --verify --configs 0:8:0:1,0:8:1:1,0:8:2:1,0:8:5:1,0:8:6:1,1:8:2:1,1:8:6:1,1:8:5:1 2>&1 | tee gpurun_out/sweep_r5.txt

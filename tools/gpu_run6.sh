@@ -1,0 +1,3 @@
+#!/bin/bash
+export TMPDIR=/tmp; mkdir -p gpurun_out
+ADLHIP_LIB=$PWD/oclradixsort_amd/lib/libadlhip_stamps.so timeout 600 python tools/stamps.py 2>&1 | tee gpurun_out/stamps_r6.txt

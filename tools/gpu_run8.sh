@@ -1,0 +1,4 @@
+#!/bin/bash
+export TMPDIR=/tmp; mkdir -p gpurun_out
+timeout 1200 python tools/sweep.py --steps 5 --verify --configs 0:8:0:1,0:8:1:1,0:8:2:1,0:8:3:1,0:8:4:1,0:8:5:1,0:8:6:1,2:8:6:1 2>&1 | tee gpurun_out/sweep_r8.txt
+ADLHIP_LIB=$PWD/oclradixsort_amd/lib/libadlhip_stamps.so timeout 600 python tools/stamps.py --configs 0:8:1:1,0:8:6:1 2>&1 | tee gpurun_out/stamps_r8.txt
