@@ -168,12 +168,13 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
 /* ---- knobs ---------------------------------------------------------------------------------- */
 
 /* Integer tunables, by name.  Unknown names fail.  Current names:
- *   "sort.algo"        0 = onesweep (single-pass per digit, decoupled look-back)  [default]
+ *   "sort.algo"        0 = onesweep (one sweep per digit, 16 decoupled look-back chains)  [default]
  *                      1 = three kernels per pass: count -> table scan -> sort+scatter (the
  *                          reference's pass structure, Pprims.cpp:357-398)
  *   "sort.digit_bits"  8 [default] or 4 (4 = the reference's R32SORT_BITS_PER_PASS, Pprims.h:31)
- *   "sort.tile"        tile geometry variant (threads x elements per thread): 0 = 256x16 [default],
- *                      1 = 512x16, 2 = 1024x16, 3 = 512x8, 4 = 1024x8, 5 = 256x32
+ *   "sort.tile"        tile geometry variant (threads x elements per thread): -1 [default] = best known
+ *                      per element size (512x32 for 4-byte, 1024x16 for 8-byte elements); 0 = 256x16,
+ *                      1 = 512x16, 2 = 1024x16, 3 = 512x8, 4 = 1024x8, 5 = 256x32, 6 = 512x32
  *   "sort.rank"        1 [default when the device self-test passes] = in-tile ranking by lane-ordered
  *                      returning LDS atomics; 0 = ranking by 64-lane ballot match
  *   "sort.lds_ordered" (read-only) result of that self-test

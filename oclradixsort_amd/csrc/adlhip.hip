@@ -69,7 +69,7 @@ struct adlhip_device {
     int sort_algo = 0;        // 0 onesweep, 1 three-kernel pass
     int digit_bits = 8;       // 8 or 4
     int profile = 0;
-    int tile_variant = 0;     // index into kVariants
+    int tile_variant = -1;    // index into kVariants; -1 = best known per element size
     int rank_mode = 1;        // 1 = lane-ordered DS atomic ranking (needs lds_ordered), 0 = ballot match
     int lds_ordered = 0;      // result of the device self-test at creation
     int wgs_per_cu = 0;       // persistent kernels: cap on resident workgroups per CU (0 = occupancy limit)
@@ -211,7 +211,19 @@ Geometry geometry(const adlhip_device* d, size_t n, uint32_t tile)
     return g;
 }
 
-uint32_t current_tile(const adlhip_device* d) { return (uint32_t)(kVariants[d->tile_variant].nt * kVariants[d->tile_variant].k); }
+// "sort.tile" = -1 (default): the measured best per element size on MI355X
+//   4-byte elements: 512 x 32 (16 Ki keys, 73 KiB of LDS, two workgroups per CU)
+//   8-byte elements: 1024 x 16 (16 Ki elements, 145 KiB of LDS, one workgroup per CU)
+int effective_variant(const adlhip_device* d, size_t elem_bytes)
+{
+    if (d->tile_variant >= 0) return d->tile_variant;
+    return elem_bytes == 4 ? 6 : 2;
+}
+uint32_t current_tile(const adlhip_device* d, size_t elem_bytes)
+{
+    const TileVariant v = kVariants[effective_variant(d, elem_bytes)];
+    return (uint32_t)(v.nt * v.k);
+}
 
 constexpr size_t kMaxElems = 0xFFF00000ull;   // 32-bit element indices inside the kernels
 
@@ -268,7 +280,7 @@ int launch_scatter(adlhip_device* d, const E* src, E* dst, const uint32_t* table
 }
 
 #define ADLHIP_DISPATCH_TILE(FN, E, NBITS, ...)                                                     \
-    switch (d->tile_variant * 2 + (d->rank_mode ? 1 : 0)) {                                         \
+    switch (effective_variant(d, sizeof(E)) * 2 + (d->rank_mode ? 1 : 0)) {                                         \
     case 0: return FN<E, NBITS, 256, 16, 0>(__VA_ARGS__);                                           \
     case 1: return FN<E, NBITS, 256, 16, 1>(__VA_ARGS__);                                           \
     case 2: return FN<E, NBITS, 512, 16, 0>(__VA_ARGS__);                                           \
@@ -297,7 +309,7 @@ template <typename E, int NBITS>
 int three_kernel_pass(adlhip_device* d, const E* src, E* dst, void* work, size_t n, int start_bit)
 {
     constexpr int kCountNT = 256;
-    const Geometry g = geometry(d, n, current_tile(d));
+    const Geometry g = geometry(d, n, current_tile(d, sizeof(E)));
     uint32_t* table = reinterpret_cast<uint32_t*>(work);
     uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + table_bytes(d, n, kMinTile));
     const uint32_t elems_per_wg = g.tiles_per_wg * g.tile;
@@ -317,14 +329,17 @@ int three_kernel_pass(adlhip_device* d, const E* src, E* dst, void* work, size_t
 // ---- onesweep --------------------------------------------------------------------------------
 
 // work buffer layout (onesweep):
-//   [ctrl: one 64-byte slot per pass holding the tile ticket; 16 passes = 1024 B]
-//   [gbase: 16 passes x 256 u32 global digit bases]
-//   [partial hist: hist_wgs x passes x 256 u32]
-//   [status: passes x num_tiles x 256 u32]
+//   [ctrl   : per pass 16 chain tickets (64 B); 16 passes = 1024 B]
+//   [tables : 16 x PassTable]
+//   [joint  : joint histograms of all passes (<= 16 passes x 16 chains x 256 bins)]
+//   [partial: hist_wgs x total_bins u32]
+//   [status : passes x status_rows x 256 u32]
 struct OnesweepLayout {
-    size_t off_ctrl, off_gbase, off_part, off_status, total;
+    size_t off_ctrl, off_tables, off_joint, off_part, off_status, total;
     uint32_t hist_wgs;
 };
+
+constexpr uint32_t kMaxJointBins = 8u * 16u * 256u;   // 64-bit keys, eight 8-bit passes (16 x 4-bit passes need less)
 
 uint32_t hist_wgs_for(const adlhip_device* d, size_t n)
 {
@@ -334,115 +349,113 @@ uint32_t hist_wgs_for(const adlhip_device* d, size_t n)
     return w ? w : 1;
 }
 
-// status rows of one pass: one per tile + one per look-back block of tiles
-size_t status_rows(uint32_t num_tiles) { return (size_t)num_tiles + num_tiles / adlhip::kLookbackBlock + 1; }
+// status rows of one pass: one per tile; every chain may add one partial tile
+size_t status_rows(size_t n, uint32_t tile) { return (n + tile - 1) / tile + adlhip::kChains + 1; }
 
 OnesweepLayout onesweep_layout(const adlhip_device* d, size_t n, int max_passes, uint32_t tile)
 {
     OnesweepLayout L;
-    uint32_t num_tiles = (uint32_t)((n + tile - 1) / tile);
-    if (num_tiles == 0) num_tiles = 1;
     L.hist_wgs = hist_wgs_for(d, n);
     L.off_ctrl = 0;
-    L.off_gbase = 1024;
-    L.off_part = L.off_gbase + (size_t)16 * 256 * 4;
-    L.off_status = align_up(L.off_part + (size_t)L.hist_wgs * max_passes * 256 * 4, 256);
-    L.total = L.off_status + (size_t)max_passes * status_rows(num_tiles) * 256 * 4;
+    L.off_tables = 1024;
+    L.off_joint = L.off_tables + sizeof(adlhip::PassTable) * adlhip::kMaxPasses;
+    L.off_part = align_up(L.off_joint + (size_t)kMaxJointBins * 4, 256);
+    L.off_status = align_up(L.off_part + (size_t)L.hist_wgs * kMaxJointBins * 4, 256);
+    L.total = L.off_status + (size_t)max_passes * status_rows(n, tile) * 256 * 4;
     return L;
 }
 
 template <typename E, int NBITS, int NT, int K, int RANK>
-int launch_onesweep(adlhip_device* d, const E* src, E* dst, const uint32_t* gbase, uint32_t* status, uint32_t* ticket,
-                    size_t n, uint32_t num_tiles, int start_bit)
+int launch_onesweep(adlhip_device* d, const E* src, E* dst, const adlhip::PassTable* table, uint32_t* status,
+                    uint32_t* tickets, size_t n, int start_bit)
 {
     using C = adlhip::TileCfg<E, NBITS, NT, K>;
-    const uint32_t status_bytes = (uint32_t)(status_rows(num_tiles) * C::BINS * 4u);
-    if (d->sort_algo == 2) {   // same tile body, one tile per workgroup (the hardware dispatcher overlaps tiles)
-        auto kern1 = adlhip::onesweep_persistent_kernel<E, NBITS, NT, K, RANK, false>;
-        if (ensure_lds(kern1, C::LDS_BYTES)) return ADLHIP_FAILURE;
-        return launch(d, kernel_name<E, NBITS>("onesweep1"), [&] {
-            hipLaunchKernelGGL(kern1, dim3(num_tiles), dim3(NT), C::LDS_BYTES, d->stream, src, dst, gbase, status,
-                               status_bytes, ticket, d->d_fault, (uint32_t)n, start_bit, num_tiles);
-        });
-    }
-    if (d->sort_algo == 3) {   // first version: thread-per-digit look-back before the LDS scatter
-        auto kern0 = adlhip::onesweep_pass_kernel<E, NBITS, NT, K, RANK>;
-        if (ensure_lds(kern0, C::LDS_BYTES)) return ADLHIP_FAILURE;
-        return launch(d, kernel_name<E, NBITS>("onesweep0"), [&] {
-            hipLaunchKernelGGL(kern0, dim3(num_tiles), dim3(NT), C::LDS_BYTES, d->stream, src, dst, gbase, status, ticket,
-                               d->d_fault, (uint32_t)n, start_bit, num_tiles);
-        });
-    }
-    auto kern = adlhip::onesweep_persistent_kernel<E, NBITS, NT, K, RANK, true>;
+    auto kern = adlhip::onesweep_chain_kernel<E, NBITS, NT, K, RANK>;
     if (ensure_lds(kern, C::LDS_BYTES)) return ADLHIP_FAILURE;
-    // persistent grid: as many workgroups as can be resident (advisory -- tiles come from a ticket, so
-    // correctness does not depend on residency), never more than there are tiles
-    static int occ = 0;   // per instantiation
-    if (occ == 0) {
-        int o = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kern, NT, C::LDS_BYTES) != hipSuccess || o < 1) o = 1;
-        occ = o;
-    }
-    int per_cu = occ;
-    if (d->wgs_per_cu > 0 && d->wgs_per_cu < per_cu) per_cu = d->wgs_per_cu;
-    uint32_t grid = (uint32_t)d->prop.multiProcessorCount * (uint32_t)per_cu;
-    if (grid > num_tiles) grid = num_tiles;
+    const size_t rows = status_rows(n, (uint32_t)C::TILE);
+    const uint32_t grid = (uint32_t)((n + C::TILE - 1) / C::TILE) + adlhip::kChains;   // upper bound on the tile count
+    const uint32_t status_bytes = (uint32_t)(rows * C::BINS * 4u);
     return launch(d, kernel_name<E, NBITS>("onesweep"), [&] {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), C::LDS_BYTES, d->stream, src, dst, gbase, status, status_bytes,
-                           ticket, d->d_fault, (uint32_t)n, start_bit, num_tiles);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), C::LDS_BYTES, d->stream, src, dst, table, status, status_bytes,
+                           tickets, d->d_fault, (uint32_t)n, start_bit);
     });
 }
 
 template <typename E, int NBITS>
-int dispatch_onesweep(adlhip_device* d, const E* src, E* dst, const uint32_t* gbase, uint32_t* status, uint32_t* ticket,
-                      size_t n, uint32_t num_tiles, int start_bit)
+int dispatch_onesweep(adlhip_device* d, const E* src, E* dst, const adlhip::PassTable* table, uint32_t* status,
+                      uint32_t* tickets, size_t n, int start_bit)
 {
-    ADLHIP_DISPATCH_TILE(launch_onesweep, E, NBITS, d, src, dst, gbase, status, ticket, n, num_tiles, start_bit)
+    ADLHIP_DISPATCH_TILE(launch_onesweep, E, NBITS, d, src, dst, table, status, tickets, n, start_bit)
 }
 
 template <typename E>
 int onesweep_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, const std::vector<PassPlan>& plan)
 {
     const int P = (int)plan.size();
-    const uint32_t tile = current_tile(d);
-    const uint32_t num_tiles = (uint32_t)((n + tile - 1) / tile);
+    const uint32_t tile = current_tile(d, sizeof(E));
     // offsets come from the worst-case layout the caller sized the buffer with
     const OnesweepLayout L = onesweep_layout(d, n, (int)(sizeof(E) == 4 ? 8 : 16), kMinTile);
     char* wb = reinterpret_cast<char*>(work);
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(wb + L.off_ctrl);
-    uint32_t* gbase = reinterpret_cast<uint32_t*>(wb + L.off_gbase);
+    adlhip::PassTable* tables = reinterpret_cast<adlhip::PassTable*>(wb + L.off_tables);
+    uint32_t* joint = reinterpret_cast<uint32_t*>(wb + L.off_joint);
     uint32_t* part = reinterpret_cast<uint32_t*>(wb + L.off_part);
     uint32_t* status = reinterpret_cast<uint32_t*>(wb + L.off_status);
+    const size_t rows = status_rows(n, tile);
 
     // zero the tickets and every status word of the passes we run (status is contiguous)
     HIPCHK(hipMemsetAsync(ctrl, 0, 1024, d->stream));
-    HIPCHK(hipMemsetAsync(status, 0, (size_t)P * status_rows(num_tiles) * 256 * 4, d->stream));
+    HIPCHK(hipMemsetAsync(status, 0, (size_t)P * rows * 256 * 4, d->stream));
 
     adlhip::PassDesc desc;
     desc.num_passes = P;
+    uint32_t total_bins = 0;
     for (int i = 0; i < P; ++i) {
         desc.start_bit[i] = (uint8_t)plan[i].start_bit;
         desc.nbits[i] = (uint8_t)plan[i].nbits;
+        total_bins += adlhip::joint_bins(plan[i].nbits);
     }
-    const uint32_t chunk = (uint32_t)align_up((n + L.hist_wgs - 1) / L.hist_wgs, 1024);
-    int rc = launch(d, sizeof(E) == 4 ? "os_hist_u32" : "os_hist_e64", [&] {
-        hipLaunchKernelGGL((adlhip::onesweep_hist_kernel<E>), dim3(L.hist_wgs), dim3(adlhip::kHistNT), 0, d->stream, data,
-                           part, (uint32_t)n, chunk, desc);
-    });
+    if (total_bins > kMaxJointBins) return fail("internal: joint histogram of %u bins exceeds %u", total_bins, kMaxJointBins);
+    // histogram workgroups nest inside the 16 input slices that are pass 0's chains
+    const uint32_t per_wg = (uint32_t)align_up((n + L.hist_wgs - 1) / L.hist_wgs, 1024);
+    const uint32_t wgs = (uint32_t)((n + per_wg - 1) / per_wg);
+    const uint32_t wgs_per_slice = (wgs + adlhip::kChains - 1) / adlhip::kChains;
+    const uint32_t slice0 = per_wg * wgs_per_slice;
+    const size_t hist_lds = (size_t)total_bins * 4;
+    int rc = ADLHIP_FAILURE;
+    auto run_hist = [&](auto kern) -> int {
+        if (ensure_lds(kern, hist_lds)) return ADLHIP_FAILURE;
+        return launch(d, sizeof(E) == 4 ? "os_hist_u32" : "os_hist_e64", [&] {
+            hipLaunchKernelGGL(kern, dim3(wgs), dim3(adlhip::kHistNT), hist_lds, d->stream, data, part, (uint32_t)n, per_wg,
+                               slice0, desc, total_bins);
+        });
+    };
+    switch (P) {   // pass count is a template parameter of the histogram kernel (descriptors stay in SGPRs)
+#define ADLHIP_HIST_CASE(N) case N: rc = run_hist(adlhip::onesweep_hist_kernel<E, N>); break;
+        ADLHIP_HIST_CASE(1) ADLHIP_HIST_CASE(2) ADLHIP_HIST_CASE(3) ADLHIP_HIST_CASE(4) ADLHIP_HIST_CASE(5)
+        ADLHIP_HIST_CASE(6) ADLHIP_HIST_CASE(7) ADLHIP_HIST_CASE(8) ADLHIP_HIST_CASE(9) ADLHIP_HIST_CASE(10)
+        ADLHIP_HIST_CASE(11) ADLHIP_HIST_CASE(12) ADLHIP_HIST_CASE(13) ADLHIP_HIST_CASE(14) ADLHIP_HIST_CASE(15)
+        ADLHIP_HIST_CASE(16)
+#undef ADLHIP_HIST_CASE
+        default: return fail("internal: %d passes", P);
+    }
     if (rc) return rc;
     rc = launch(d, "os_hist_reduce", [&] {
-        hipLaunchKernelGGL(adlhip::onesweep_hist_reduce_kernel, dim3(P), dim3(1024), 0, d->stream, part, gbase,
-                           L.hist_wgs, P);
+        hipLaunchKernelGGL(adlhip::onesweep_hist_reduce_kernel, dim3((total_bins + 255) / 256), dim3(1024), 0, d->stream,
+                           part, joint, wgs, total_bins);
+    });
+    if (rc) return rc;
+    rc = launch(d, "os_tables", [&] {
+        hipLaunchKernelGGL(adlhip::onesweep_tables_kernel, dim3(P), dim3(256), 0, d->stream, joint, tables, desc, tile);
     });
     if (rc) return rc;
 
     E* src = data;
     E* dst = tmp;
     for (int i = 0; i < P; ++i) {
-        uint32_t* st = status + (size_t)i * status_rows(num_tiles) * 256;
-        rc = (plan[i].nbits == 8)
-                 ? dispatch_onesweep<E, 8>(d, src, dst, gbase + i * 256, st, ctrl + i * 16, n, num_tiles, plan[i].start_bit)
-                 : dispatch_onesweep<E, 4>(d, src, dst, gbase + i * 256, st, ctrl + i * 16, n, num_tiles, plan[i].start_bit);
+        uint32_t* st = status + (size_t)i * rows * 256;
+        rc = (plan[i].nbits == 8) ? dispatch_onesweep<E, 8>(d, src, dst, tables + i, st, ctrl + i * 16, n, plan[i].start_bit)
+                                  : dispatch_onesweep<E, 4>(d, src, dst, tables + i, st, ctrl + i * 16, n, plan[i].start_bit);
         if (rc) return rc;
         std::swap(src, dst);
     }
@@ -555,8 +568,8 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         d->lds_ordered = (ok && mism == 0) ? 1 : 0;
         d->rank_mode = d->lds_ordered;
     }
-    if (const char* a = getenv("ADLHIP_SORT_ALGO")) { int v = atoi(a); if (v >= 0 && v <= 3) d->sort_algo = v; }
-    if (const char* t = getenv("ADLHIP_SORT_TILE")) { int v = atoi(t); if (v >= 0 && v < kNumVariants) d->tile_variant = v; }
+    if (const char* a = getenv("ADLHIP_SORT_ALGO")) { int v = atoi(a); if (v == 0 || v == 1) d->sort_algo = v; }
+    if (const char* t = getenv("ADLHIP_SORT_TILE")) { int v = atoi(t); if (v >= -1 && v < kNumVariants) d->tile_variant = v; }
     if (const char* r = getenv("ADLHIP_SORT_RANK")) d->rank_mode = (atoi(r) && d->lds_ordered) ? 1 : 0;
     if (const char* b = getenv("ADLHIP_DIGIT_BITS")) d->digit_bits = (atoi(b) == 4) ? 4 : 8;
     *out = d;
@@ -868,13 +881,13 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
 {
     if (!d || !name) return fail("null argument");
     if (!strcmp(name, "sort.algo")) {
-        if (value < 0 || value > 3) return fail("sort.algo must be in [0,3]");
+        if (value != 0 && value != 1) return fail("sort.algo must be 0 or 1");
         d->sort_algo = value;
     } else if (!strcmp(name, "sort.digit_bits")) {
         if (value != 4 && value != 8) return fail("sort.digit_bits must be 4 or 8");
         d->digit_bits = value;
     } else if (!strcmp(name, "sort.tile")) {
-        if (value < 0 || value >= kNumVariants) return fail("sort.tile must be in [0,%d)", kNumVariants);
+        if (value < -1 || value >= kNumVariants) return fail("sort.tile must be in [-1,%d)", kNumVariants);
         d->tile_variant = value;
     } else if (!strcmp(name, "sort.wgs_per_cu")) {
         if (value < 0 || value > 16) return fail("sort.wgs_per_cu must be in [0,16]");

@@ -18,11 +18,11 @@ from oclradixsort_amd import AdlHipError, Buffer, DeviceUtils, Pprims, Stopwatch
 pytestmark = pytest.mark.gpu
 
 # (sort.algo, sort.digit_bits, sort.tile, sort.rank)
-ALGOS = [(0, 8, 0, 1), (0, 4, 0, 1), (1, 8, 0, 1), (1, 4, 0, 1), (0, 8, 0, 0), (1, 8, 0, 0), (0, 8, 2, 1), (1, 8, 1, 1),
-         (0, 8, 3, 1), (1, 8, 4, 0), (0, 8, 5, 1)]
-ALGO_IDS = ["onesweep8", "onesweep4", "threekernel8", "threekernel4", "onesweep8-ballot", "threekernel8-ballot",
-            "onesweep8-1024x16", "threekernel8-512x16", "onesweep8-512x8", "threekernel8-1024x8-ballot",
-            "onesweep8-256x32"]
+ALGOS = [(0, 8, -1, 1), (0, 4, -1, 1), (1, 8, -1, 1), (1, 4, -1, 1), (0, 8, -1, 0), (1, 8, 0, 0), (0, 8, 0, 1), (1, 8, 1, 1),
+         (0, 8, 3, 1), (1, 8, 4, 0), (0, 8, 5, 1), (0, 8, 2, 1), (0, 4, 0, 0)]
+ALGO_IDS = ["onesweep8", "onesweep4", "threekernel8", "threekernel4", "onesweep8-ballot", "threekernel8-256x16-ballot",
+            "onesweep8-256x16", "threekernel8-512x16", "onesweep8-512x8", "threekernel8-1024x8-ballot",
+            "onesweep8-256x32", "onesweep8-1024x16", "onesweep4-256x16-ballot"]
 
 
 @pytest.fixture(scope="module")
@@ -34,7 +34,7 @@ def dev():
 
 @pytest.fixture()
 def pp(dev):
-    set_algo(dev, (0, 8, 0))
+    set_algo(dev, (0, 8, -1))
     p = Pprims()
     yield p
     p.close()
@@ -298,7 +298,7 @@ def test_scan_sizes_and_inplace(dev, pp):
 def test_lookback_under_repeated_uneven_launches(dev, pp):
     """Hammer the tile-status protocol: many back-to-back sorts of different sizes on one stream, checked
     only at the end (no sync in between), plus a fault-word check at sync."""
-    set_algo(dev, (0, 8))
+    set_algo(dev, (0, 8, -1))
     sizes = [1 << 20, 777777, 4097, 3 << 20, 123456, 5 << 20, 65536]
     bufs, wants = [], []
     for i, n in enumerate(sizes):
@@ -325,7 +325,7 @@ def _checksums(a):
     return int(a64.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(a64)), int((a64 * a64).sum(dtype=np.uint64))
 
 
-@pytest.mark.parametrize("algo", [(0, 8), (1, 8)], ids=["onesweep8", "threekernel8"])
+@pytest.mark.parametrize("algo", [(0, 8, -1), (1, 8, -1)], ids=["onesweep8", "threekernel8"])
 def test_full_size_64m_u32(dev, pp, algo):
     set_algo(dev, algo)
     n = 1 << 26

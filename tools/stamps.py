@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oclradixsort_amd import Buffer, DeviceUtils, Pprims, _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=1 << 26)
-ap.add_argument("--configs", default="0:8:6:1,2:8:6:1,3:8:6:1")
+ap.add_argument("--configs", default="0:8:6:1,0:8:1:1")
 args = ap.parse_args()
 n = args.n
 d = DeviceUtils.allocate(); p = Pprims()
@@ -18,8 +18,8 @@ TILES_MAX = (n + 4095) // 4096
 stamps = Buffer(d, TILES_MAX * 16, np.uint64)
 old_names = {(11, 0): "ticket", (0, 1): "load", (1, 2): "rank", (2, 3): "barA", (3, 4): "perbin+scan", (4, 5): "lookback",
              (5, 6): "bar", (6, 7): "lds-scatter", (7, 8): "bar", (8, 9): "write-out", (9, 10): "bar"}
-new_names = {(0, 2): "zero+wait-loads+rank", (2, 3): "barA", (3, 4): "bookkeeping(w0)", (4, 5): "barB", (5, 6): "lds-scatter",
-             (6, 7): "lookback(w0)", (7, 8): "prefetch-issue", (8, 9): "barC", (9, 10): "write-out"}
+new_names = {(0, 2): "load+rank", (2, 3): "barA", (3, 4): "bookkeeping(w0)", (4, 5): "barB", (5, 6): "lds-scatter",
+             (6, 7): "lookback(w0)", (7, 9): "barC", (9, 10): "write-out"}
 tiles_of = {0: 4096, 1: 8192, 2: 16384, 3: 4096, 4: 8192, 5: 8192, 6: 16384}
 buf = Buffer(d, n, np.uint32)
 for cfg in args.configs.split(","):
@@ -30,7 +30,7 @@ for cfg in args.configs.split(","):
     assert lib.adlhip_debug_set_stamp_buffer(d._h, stamps.ptr()) == 0
     p.radixSort(d, buf, n, 8)          # ONE 8-bit pass so the stamps belong to a single kernel launch
     s = stamps.toHost().reshape(-1, 16)
-    nt = (n + tiles_of[tile] - 1) // tiles_of[tile]
+    nt = (n + tiles_of[tile] - 1) // tiles_of[tile] + 16
     s = s[:nt].astype(np.int64)
     print("config %s: %d tiles of %d keys" % (cfg, nt, tiles_of[tile]))
     names = new_names if algo in (0, 2) else old_names
@@ -40,20 +40,6 @@ for cfg in args.configs.split(","):
             continue
         dlt = (s[ok, b] - s[ok, a])
         print("   %-28s mean %8.0f  p50 %8.0f  p90 %8.0f cycles" % (nm + "(%d>%d)" % (a, b), dlt.mean(), np.median(dlt), np.percentile(dlt, 90)))
-    if algo in (0, 2):
-        ok = (s[:, 6] > 0) & (s[:, 12] > 0)
-        d1 = s[ok, 12] - s[ok, 6]
-        print("   look-back: tile rows of own block (6>12)   mean %8.0f p50 %8.0f p90 %8.0f" % (d1.mean(), np.median(d1), np.percentile(d1, 90)))
-        ok = (s[:, 12] > 0) & (s[:, 13] > 0)
-        d2 = s[ok, 13] - s[ok, 12]
-        print("   look-back: first block-prefix load (12>13) mean %8.0f p50 %8.0f p90 %8.0f" % (d2.mean(), np.median(d2), np.percentile(d2, 90)))
-        ok = s[:, 14] > 0
-        polls = s[ok, 14] - 1
-        first_ready = (polls >= 1000)
-        pl = np.where(first_ready, polls - 1000, polls)
-        walked = s[ok, 15] - 1
-        print("   block prefix ready on first load: %.1f%%; extra polls mean %.2f max %d; blocks walked mean %.2f max %d" % (
-            100.0 * first_ready.mean(), pl.mean(), pl.max(), walked.mean(), walked.max()))
     ok = (s[:, 0] > 0) & (s[:, 10] > 0)
     life = (s[ok, 10] - s[ok, 0])
     print("   tile lifetime (0>10) mean %.0f cycles" % life.mean())
