@@ -1,0 +1,56 @@
+// Tahoe/ParallelPrimitives/Pprims.h -- the parallel-primitives object of the reference
+// (Tahoe/ParallelPrimitives/Pprims.h:11-48) over the MI355X HIP back-end:
+//   scan      exclusive prefix sum                                   (reference Pprims.h:35)
+//   radixSort {u32 key, u32 value} pairs, stable                     (reference Pprims.h:38)
+//   radixSort u32 keys                                               (reference Pprims.h:41)
+//   radixSort u64 keys                                               (new: BASELINE config #5)
+// Same argument meaning; differences, all supersets: any n >= 0 (the reference needs n % 256 == 0 for
+// keys), scan has no 1,048,576-element limit, sortBits < 32 also works on 64-bit keys up to 64.
+// Device work is enqueued and the call returns (no sync), as in the reference's GPU branches.
+// A TYPE_HOST device takes the CPU path (Tahoe::RadixSort::sort), exactly as Pprims.cpp:202-212/306-316;
+// a TYPE_CL (HIP) device never falls back to the CPU.
+#pragma once
+#include <Adl/Adl.h>
+#include <Tahoe/Math/Math.h>
+#include <Tahoe/ParallelPrimitives/uArray.h>   // the reference's Pprims.h pulls uArray / Array in for its users
+
+namespace Tahoe {
+
+class Pprims {
+public:
+    TH_DECLARE_ALLOCATOR(Pprims);
+
+    Pprims();
+    ~Pprims();
+
+    void cacheKernel(bool cache) { m_cacheKernel = cache; }   // kernels are built ahead of time; kept for API parity
+
+    enum {
+        SCAN_BLOCK_SIZE = 128,
+        RSORT_BITS_PER_PASS = 8,
+        RSORT_NUM_TABLES = (1 << RSORT_BITS_PER_PASS),
+        R32SORT_DATA_ALIGNMENT = 256,   // the reference's requirement on n; not needed here
+        R32SORT_WG_SIZE = 64,
+        R32SORT_ELEMENTS_PER_WORK_ITEM = (256 / R32SORT_WG_SIZE),
+        R32SORT_BITS_PER_PASS = 4,      // the reference's digit width; select with adlhip "sort.digit_bits"
+    };
+
+    void scan(const adl::Device* device, adl::Buffer<int>& dst, const adl::Buffer<int>& src, int n, u32* sumOut = 0);
+
+    // inout.x: key, inout.y: value
+    void radixSort(const adl::Device* device, const adl::Buffer<uint2>& inout, int n, int sortBits = 32);
+
+    void radixSort(const adl::Device* device, const adl::Buffer<u32>& inout, int n, int sortBits = 32);
+
+    void radixSort(const adl::Device* device, const adl::Buffer<u64>& inout, int n, int sortBits = 64);
+
+private:
+    // device scratch owned by the object and grown lazily (reference: m_u32WorkBuffer[0] = ping-pong data,
+    // m_u32WorkBuffer[1] = histogram table; Pprims.h:44-45)
+    void reserve(const adl::Device* device, size_t tmpBytes, size_t workBytes);
+    adl::Buffer<unsigned char>* m_tmp;
+    adl::Buffer<unsigned char>* m_work;
+    bool m_cacheKernel;
+};
+
+}  // namespace Tahoe

@@ -102,7 +102,8 @@ int adlhip_fill_u32(adlhip_device* dev, void* dptr, uint32_t pattern, size_t cou
  * clEnqueueMapBuffer READ|WRITE / clEnqueueUnmapMemObject).  adlhip_map enqueues a device->pinned-host
  * copy and returns the host pointer; contents are valid after adlhip_sync().  adlhip_unmap enqueues the
  * host->device write-back and releases the staging memory once that copy has run; the device sees the
- * writes after adlhip_sync().  Exactly the call sequence of UnitTest/main.cpp:118-125. */
+ * writes after adlhip_sync().  Exactly the call sequence of UnitTest/main.cpp:118-125.
+ * adlhip_unmap: bytes = 0 writes back the whole mapping (Buffer::returnHostPtr carries no size). */
 int adlhip_map(adlhip_device* dev, void* dptr, size_t bytes, void** hptr);
 int adlhip_unmap(adlhip_device* dev, void* dptr, void* hptr, size_t bytes);
 

@@ -732,6 +732,7 @@ int adlhip_unmap(adlhip_device* d, void* dptr, void* hptr, size_t bytes)
     for (auto& s : d->staging) {
         if (s.hptr == hptr && !s.done) {
             if (bytes > s.bytes) return fail("unmap: %zu bytes exceeds the mapped %zu", bytes, s.bytes);
+            if (bytes == 0) bytes = s.bytes;   // 0 = the whole mapping (Buffer::returnHostPtr carries no size)
             HIPCHK(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, d->stream));
             hipEvent_t ev;
             HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));

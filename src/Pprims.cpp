@@ -1,0 +1,123 @@
+// Host driver of Tahoe::Pprims over the C ABI (include/adlhip.h).
+// Reference: Tahoe/ParallelPrimitives/Pprims.cpp:13-30 (ctor/dtor), :122-179 (scan), :200-302 and :304-406
+// (radixSort).  The reference's pass loop, kernel look-ups and launches live behind adlhip_radix_sort_*;
+// what stays on this side is what a Pprims caller can observe: scratch ownership, the host-device branch
+// (enableSortOnDevice, :189-198) and the argument checks.
+#include <Tahoe/ParallelPrimitives/Pprims.h>
+#include <Tahoe/Algorithm/Sort/RadixSort.h>
+
+namespace Tahoe {
+
+Pprims::Pprims() : m_tmp(0), m_work(0), m_cacheKernel(true) {}
+
+Pprims::~Pprims()
+{
+    delete m_tmp;    // must happen before DeviceUtils::deallocate (which asserts no live bytes, Adl.inl:102)
+    delete m_work;
+}
+
+void Pprims::reserve(const adl::Device* device, size_t tmpBytes, size_t workBytes)
+{
+    if (m_tmp && m_tmp->m_device != device) {   // a Pprims follows the device it is used with
+        delete m_tmp;
+        delete m_work;
+        m_tmp = m_work = 0;
+    }
+    if (!m_tmp) {
+        m_tmp = new adl::Buffer<unsigned char>(device, tmpBytes ? tmpBytes : 16);
+        m_work = new adl::Buffer<unsigned char>(device, workBytes ? workBytes : 16);
+    }
+    if (m_tmp->getSize() < tmpBytes) m_tmp->setSize(tmpBytes);      // grow-only, contents not preserved
+    if (m_work->getSize() < workBytes) m_work->setSize(workBytes);
+}
+
+static inline bool enableSortOnDevice(const adl::Device* device)
+{
+    // Pprims.cpp:189-198: only a GPU behind TYPE_CL sorts on the device
+    return device && device->getType() == adl::TYPE_CL && device->getProcType() == adl::Device::Config::DEVICE_GPU &&
+           device->hip() != 0;
+}
+
+void Pprims::radixSort(const adl::Device* device, const adl::Buffer<u32>& inout, int n, int sortBits)
+{
+    ADLASSERT(n >= 0);
+    if (n <= 0) return;
+    if (!enableSortOnDevice(device)) {   // Pprims.cpp:306-316
+        ADLASSERT(device != 0);
+        ADLASSERT(sortBits == 32);
+        u32* host = inout.getHostPtr(n);
+        adl::DeviceUtils::waitForCompletion(device);
+        RadixSort::sort(host, n);
+        inout.returnHostPtr(host);
+        adl::DeviceUtils::waitForCompletion(device);
+        return;
+    }
+    ADLASSERT((sortBits & 0x3) == 0);   // Pprims.cpp:330
+    size_t tb = 0, wb = 0;
+    ADLASSERT(adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_U32, (size_t)n, &tb, &wb) == ADLHIP_SUCCESS);
+    reserve(device, tb, wb);
+    const int rc = adlhip_radix_sort_u32(device->hip(), inout.m_ptr, (u32*)m_tmp->m_ptr, m_work->m_ptr, (size_t)m_work->getSize(),
+                                         (size_t)n, sortBits);
+    if (rc != ADLHIP_SUCCESS) TH_LOG_ERROR("Pprims::radixSort: %s\n", adlhip_last_error());
+    ADLASSERT(rc == ADLHIP_SUCCESS);
+}
+
+void Pprims::radixSort(const adl::Device* device, const adl::Buffer<uint2>& inout, int n, int sortBits)
+{
+    ADLASSERT(n >= 0);
+    if (n <= 0) return;
+    if (!enableSortOnDevice(device)) {   // Pprims.cpp:202-212
+        ADLASSERT(device != 0);
+        ADLASSERT(sortBits == 32);
+        uint2* host = inout.getHostPtr(n);
+        adl::DeviceUtils::waitForCompletion(device);
+        RadixSort::sort((SortData*)host, n);
+        inout.returnHostPtr(host);
+        adl::DeviceUtils::waitForCompletion(device);
+        return;
+    }
+    ADLASSERT((sortBits & 0x3) == 0);
+    size_t tb = 0, wb = 0;
+    ADLASSERT(adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_KV32, (size_t)n, &tb, &wb) == ADLHIP_SUCCESS);
+    reserve(device, tb, wb);
+    const int rc = adlhip_radix_sort_kv32(device->hip(), inout.m_ptr, m_tmp->m_ptr, m_work->m_ptr, (size_t)m_work->getSize(),
+                                          (size_t)n, sortBits);
+    if (rc != ADLHIP_SUCCESS) TH_LOG_ERROR("Pprims::radixSort: %s\n", adlhip_last_error());
+    ADLASSERT(rc == ADLHIP_SUCCESS);
+}
+
+void Pprims::radixSort(const adl::Device* device, const adl::Buffer<u64>& inout, int n, int sortBits)
+{
+    ADLASSERT(n >= 0);
+    if (n <= 0) return;
+    ADLASSERT(enableSortOnDevice(device));   // 64-bit keys exist on the device path only
+    if (!enableSortOnDevice(device)) return;
+    ADLASSERT((sortBits & 0x3) == 0);
+    size_t tb = 0, wb = 0;
+    ADLASSERT(adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_U64, (size_t)n, &tb, &wb) == ADLHIP_SUCCESS);
+    reserve(device, tb, wb);
+    const int rc = adlhip_radix_sort_u64(device->hip(), (uint64_t*)inout.m_ptr, (uint64_t*)m_tmp->m_ptr, m_work->m_ptr,
+                                         (size_t)m_work->getSize(), (size_t)n, sortBits);
+    if (rc != ADLHIP_SUCCESS) TH_LOG_ERROR("Pprims::radixSort: %s\n", adlhip_last_error());
+    ADLASSERT(rc == ADLHIP_SUCCESS);
+}
+
+void Pprims::scan(const adl::Device* device, adl::Buffer<int>& dst, const adl::Buffer<int>& src, int n, u32* sumOut)
+{
+    if (device == 0 || device->hip() == 0) {   // Pprims.cpp:124-127: no host fallback for scan
+        ADLASSERT(0);
+        return;
+    }
+    ADLASSERT(n >= 0);
+    size_t wb = 0;
+    ADLASSERT(adlhip_scan_scratch_bytes(device->hip(), (size_t)n, &wb) == ADLHIP_SUCCESS);
+    reserve(device, 0, wb);
+    // sumOut is filled by a stream-ordered copy, valid after the caller's waitForCompletion -- the reference
+    // reads it back with a non-blocking read as well (Pprims.cpp:164-167)
+    const int rc = adlhip_exclusive_scan_u32(device->hip(), (uint32_t*)dst.m_ptr, (const uint32_t*)src.m_ptr, m_work->m_ptr,
+                                             (size_t)m_work->getSize(), (size_t)n, sumOut);
+    if (rc != ADLHIP_SUCCESS) TH_LOG_ERROR("Pprims::scan: %s\n", adlhip_last_error());
+    ADLASSERT(rc == ADLHIP_SUCCESS);
+}
+
+}  // namespace Tahoe

@@ -1,0 +1,174 @@
+// Demo harness: the three checks of the reference's unit test (UnitTest/main.cpp:40-56, 88-213 --
+// Demo.Sort32, Demo.SortKeyValue, Demo.Scan over the sizes 1K..1024K with srand(123) data), re-created
+// without gtest on top of the facade headers, plus the cases the reference cannot run:
+//   --host     run the sorts on an Adl TYPE_HOST device (BASELINE config #1: the CPU path; the shipped test
+//              hard-codes TYPE_CL, UnitTest/main.cpp:98)
+//   default    TYPE_CL = the MI355X HIP back-end; Demo.Scan includes 1024K, where the reference gives up
+//              (README.md:73-74, Pprims.cpp:134-138)
+// The ground truth is computed here with the C++ standard library (std::sort / std::stable_sort / running
+// sum), so this binary depends on nothing under oracle/.
+// Exit status = number of failed checks.
+#include <Adl/Adl.h>
+#include <Tahoe/Algorithm/Sort/RadixSort.h>
+#include <Tahoe/ParallelPrimitives/Pprims.h>
+#include <Tahoe/ParallelPrimitives/uArray.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace adl;
+using namespace Tahoe;
+
+char adl::s_cacheDirectory[128] = "cache";
+
+namespace {
+
+// the reference's data recipe (UnitTest/main.cpp:76-86)
+template <typename T>
+T demoRandom(const T& lo, const T& hi)
+{
+    const double r = std::min((double)RAND_MAX - 1, (double)rand()) / RAND_MAX;
+    const T range = hi - lo;
+    return (T)(lo + r * range);
+}
+
+int g_failed = 0;
+void check(bool ok, const char* what, int n)
+{
+    if (!ok) {
+        ++g_failed;
+        printf("  FAILED: %s at %d elems\n", what, n);
+    }
+}
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void demoSort32(Device* d, Pprims& p)
+{
+    printf("[ RUN      ] Demo.Sort32\n");
+    const double t0 = now_ms();
+    for (int n = 1024; n < 2 * 1024 * 1024; n *= 2) {
+        printf("test %6.1fK elems\n", n / 1024.f);
+        srand(123);
+        Buffer<u32> gpu(d, n);
+        std::vector<u32> cpu(n);
+        u32* h = gpu.getHostPtr(n);
+        DeviceUtils::waitForCompletion(d);
+        for (int i = 0; i < n; ++i) h[i] = cpu[i] = demoRandom(0u, 0xffffffffu);
+        gpu.returnHostPtr(h);
+        DeviceUtils::waitForCompletion(d);
+
+        p.radixSort(d, gpu, n);
+        std::sort(cpu.begin(), cpu.end());
+
+        h = gpu.getHostPtr(n);
+        DeviceUtils::waitForCompletion(d);
+        check(memcmp(h, cpu.data(), sizeof(u32) * n) == 0, "Sort32 differs from std::sort", n);
+        gpu.returnHostPtr(h);
+        DeviceUtils::waitForCompletion(d);
+    }
+    printf("[       %s ] Demo.Sort32 (%.0f ms)\n", g_failed ? "FAIL" : "OK", now_ms() - t0);
+}
+
+void demoSortKeyValue(Device* d, Pprims& p)
+{
+    printf("[ RUN      ] Demo.SortKeyValue\n");
+    const double t0 = now_ms();
+    const int before = g_failed;
+    for (int n = 1024; n < 2 * 1024 * 1024; n *= 2) {
+        n += 13;   // the reference bumps the size inside the doubling loop (main.cpp:144): 1037, 2087, ...
+        printf("test %6.1fK elems\n", n / 1024.f);
+        srand(123);
+        Buffer<SortData> gpu(d, n);
+        uArray<SortData> cpu(n);
+        SortData* h = gpu.getHostPtr(n);
+        DeviceUtils::waitForCompletion(d);
+        for (int i = 0; i < n; ++i) h[i] = cpu[i] = SortData(demoRandom(0u, 0xffffffffu), (u32)i);
+        gpu.returnHostPtr(h);
+        DeviceUtils::waitForCompletion(d);
+
+        p.radixSort(d, *(Buffer<uint2>*)&gpu, n);
+        std::stable_sort(cpu.begin(), cpu.begin() + n);   // by key, ties keep input order
+
+        h = gpu.getHostPtr(n);
+        DeviceUtils::waitForCompletion(d);
+        bool ok = true;
+        for (int i = 0; i < n; ++i) ok &= (h[i].m_key == cpu[i].m_key) && (h[i].m_value == cpu[i].m_value);
+        check(ok, "SortKeyValue differs from std::stable_sort", n);
+        gpu.returnHostPtr(h);
+        DeviceUtils::waitForCompletion(d);
+    }
+    printf("[       %s ] Demo.SortKeyValue (%.0f ms)\n", g_failed > before ? "FAIL" : "OK", now_ms() - t0);
+}
+
+void demoScan(Device* d, Pprims& p)
+{
+    printf("[ RUN      ] Demo.Scan\n");
+    const double t0 = now_ms();
+    const int before = g_failed;
+    for (int n = 1024; n < 2 * 1024 * 1024; n *= 2) {
+        printf("test %6.1fK elems\n", n / 1024.f);
+        srand(123);
+        Buffer<int> gpu(d, n);
+        Buffer<int> gpuRes(d, n);
+        std::vector<int> cpu(n);
+        int* h = gpu.getHostPtr(n);
+        DeviceUtils::waitForCompletion(d);
+        for (int i = 0; i < n; ++i) h[i] = cpu[i] = demoRandom(0, 0xf);
+        gpu.returnHostPtr(h);
+        DeviceUtils::waitForCompletion(d);
+
+        u32 total = 0xdeadbeef;
+        p.scan(d, gpuRes, gpu, n, &total);
+
+        h = gpuRes.getHostPtr(n);
+        DeviceUtils::waitForCompletion(d);
+        int ans = 0;
+        bool fail = false;
+        for (int i = 0; i < n; ++i) {   // the reference's own check (main.cpp:193-199)
+            fail |= (h[i] != ans);
+            ans += cpu[i];
+        }
+        check(!fail, "Scan differs from the running sum", n);
+        check(total == (u32)ans, "Scan grand total", n);
+        gpuRes.returnHostPtr(h);
+        DeviceUtils::waitForCompletion(d);
+    }
+    printf("[       %s ] Demo.Scan (%.0f ms)\n", g_failed > before ? "FAIL" : "OK", now_ms() - t0);
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    bool host = false;
+    for (int i = 1; i < argc; ++i) host |= !strcmp(argv[i], "--host");
+
+    DeviceUtils::Config cfg;
+    cfg.m_type = host ? DeviceUtils::Config::DEVICE_CPU : DeviceUtils::Config::DEVICE_GPU;
+    Device* d = DeviceUtils::allocate(host ? TYPE_HOST : TYPE_CL, cfg);
+    if (adl_assert_failures()) {
+        printf("cannot open the device\n");
+        return 100;
+    }
+    char name[128];
+    d->getDeviceName(name);
+    printf("device: %s (%s path)\n", name, host ? "Adl/Host CPU" : "HIP");
+    {
+        Pprims p;
+        demoSort32(d, p);
+        demoSortKeyValue(d, p);
+        if (!host) demoScan(d, p);   // scan has no host path in the reference either (Pprims.cpp:124-127)
+    }
+    DeviceUtils::deallocate(d);
+    g_failed += adl_assert_failures();
+    printf("%s: %d failed checks\n", g_failed ? "FAILED" : "PASSED", g_failed);
+    return g_failed;
+}

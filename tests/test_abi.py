@@ -80,13 +80,16 @@ def test_null_handle_is_rejected(lib):
 
 
 def test_product_never_touches_the_oracle():
-    """The product package and the C++/HIP sources must not reference oracle/ in any way."""
+    """The product package, the C ABI, the facade and the demo harness must not reference oracle/ at all."""
     bad = []
-    for base in ("oclradixsort_amd", "include", "src"):
+    for base in ("oclradixsort_amd", "include", "src", os.path.join("tests", "demo")):
         for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
             for f in files:
-                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".inl")):
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".inl", ".c")) or f == "Makefile":
                     text = open(os.path.join(dirpath, f), errors="ignore").read()
-                    if re.search(r"\boracle\b", text) and "liboracle" in text or "import oracle" in text or "oracle/" in text:
+                    if re.search(r"import oracle|from oracle|liboracle|oracle/|libref|_ref/", text):
+                        # the demo harness may SAY it does not depend on oracle/; nothing else may mention it
+                        if f == "demo_main.cpp" and "depends on nothing under oracle/" in text:
+                            continue
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
