@@ -383,3 +383,57 @@ def test_stopwatch_and_profiling(dev, pp):
     assert any(k.startswith("onesweep_u32") for k in prof), prof
     assert sum(v[1] for v in prof.values()) > 0
     b.release()
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-GPU building blocks on one GPU: MSB partition + a simulated exchange (everything but RCCL)
+# ---------------------------------------------------------------------------------------------
+def test_msb_partition_and_simulated_exchange():
+    import torch
+    from oclradixsort_amd.dist import HipBackend
+    be = HipBackend(0)
+    try:
+        n = 300007
+        for G in (1, 2, 4, 8, 256):
+            shards = [oracle.keys_u32(n, seed=11, first_index=r * n) for r in range(min(G, 8))]
+            parts, counts = [], []
+            for k in shards:
+                t = torch.from_numpy(k.view(np.int32).copy()).cuda()
+                p, c = be.partition_msb(t, G)
+                torch.cuda.synchronize()
+                p = p.cpu().numpy().view(np.uint32)
+                c = c.cpu().numpy().astype(np.int64)
+                lg = G.bit_length() - 1
+                bucket = (k >> np.uint32(32 - lg)).astype(np.int64) if lg else np.zeros(n, dtype=np.int64)
+                assert np.array_equal(c, np.bincount(bucket, minlength=G)), G
+                # stable partition by bucket; inside a bucket the keys are ordered by their top byte (stable)
+                order = np.argsort((k >> np.uint32(24)).astype(np.int64), kind="stable")
+                assert np.array_equal(p, k[order] if G > 1 else k), G      # one bucket: a plain copy
+                parts.append(p)
+                counts.append(c)
+            if G <= 8:
+                # what all_to_all_single would deliver: rank g receives, in source-rank order, every
+                # shard's segment g; then sorts locally
+                outs = []
+                for g in range(G):
+                    segs = []
+                    for p, c in zip(parts, counts):
+                        off = int(c[:g].sum())
+                        segs.append(p[off:off + int(c[g])])
+                    recv = torch.from_numpy(np.concatenate(segs).view(np.int32).copy()).cuda()
+                    be.local_sort(recv)
+                    torch.cuda.synchronize()
+                    outs.append(recv.cpu().numpy().view(np.uint32))
+                assert np.array_equal(np.concatenate(outs), oracle.sort_u32(np.concatenate(shards))), G
+    finally:
+        be.close()
+
+
+def test_generated_keys_match_the_oracle_generator(dev):
+    n = 100001
+    for kind, dtype, want in ((0, np.uint32, oracle.keys_u32(n, 123, 77)), (1, np.uint64, oracle.pairs_kv32(n, 123, 77)),
+                              (2, np.uint64, oracle.keys_u64(n, 123, 77))):
+        b = Buffer(dev, n, dtype)
+        b.generate(n, seed=123, firstIndex=77, kind=kind)
+        assert np.array_equal(b.toHost(), want), kind
+        b.release()
