@@ -181,9 +181,21 @@ def main():
         dom_name, (dom_launches, dom_ms) = max(scatter.items(), key=lambda kv: kv[1][1])
         dom_avg_s = dom_ms / dom_launches * 1e-3
         achieved = 2.0 * n * ELEM_BYTES / dom_avg_s / 1e9
+        # HBM traffic per launch from PMC counters: collected in separate rocprofv3 --pmc passes of this same
+        # command (tools/gpu_session.sh) and stored under profiles/; used only if it is for this kernel and size
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+                t = json.load(open(f))
+                if t.get("profile_name") == dom_name and t.get("keys_per_launch") == n:
+                    traffic, traffic_src = t["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+                    break
+        except Exception:
+            pass
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": dom_name, "launches": dom_launches, "avg_launch_ms": dom_ms / dom_launches,
             "algorithmic_bytes_per_launch": 2 * n * ELEM_BYTES,
             "timing": "hipEvent pair around every launch on the library's stream, second loop over the same K inputs",

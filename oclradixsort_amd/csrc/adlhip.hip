@@ -72,7 +72,6 @@ struct adlhip_device {
     int tile_variant = -1;    // index into kVariants; -1 = best known per element size
     int rank_mode = 1;        // 1 = lane-ordered DS atomic ranking (needs lds_ordered), 0 = ballot match
     int lds_ordered = 0;      // result of the device self-test at creation
-    int wgs_per_cu = 0;       // persistent kernels: cap on resident workgroups per CU (0 = occupancy limit)
     // profiling
     std::vector<PendingProf> pending;
     std::vector<hipEvent_t> event_pool;
@@ -343,7 +342,7 @@ constexpr uint32_t kMaxJointBins = 8u * 16u * 256u;   // 64-bit keys, eight 8-bi
 
 uint32_t hist_wgs_for(const adlhip_device* d, size_t n)
 {
-    const uint32_t cap = (uint32_t)d->prop.multiProcessorCount;   // one 1024-thread workgroup per CU
+    const uint32_t cap = (uint32_t)d->prop.multiProcessorCount;   // one 1024-thread workgroup per CU (2 or 4 measured slower)
     uint32_t w = (uint32_t)((n + adlhip::kHistChunk - 1) / adlhip::kHistChunk);
     if (w > cap) w = cap;
     return w ? w : 1;
@@ -890,9 +889,7 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
     } else if (!strcmp(name, "sort.tile")) {
         if (value < -1 || value >= kNumVariants) return fail("sort.tile must be in [-1,%d)", kNumVariants);
         d->tile_variant = value;
-    } else if (!strcmp(name, "sort.wgs_per_cu")) {
-        if (value < 0 || value > 16) return fail("sort.wgs_per_cu must be in [0,16]");
-        d->wgs_per_cu = value;
+
     } else if (!strcmp(name, "sort.rank")) {
         if (value != 0 && value != 1) return fail("sort.rank must be 0 or 1");
         if (value == 1 && !d->lds_ordered) return fail("sort.rank = 1 needs lane-ordered DS atomics; the device self-test failed");
@@ -914,7 +911,6 @@ int adlhip_get_param(adlhip_device* d, const char* name, int* value)
     else if (!strcmp(name, "sort.digit_bits")) *value = d->digit_bits;
     else if (!strcmp(name, "sort.tile")) *value = d->tile_variant;
     else if (!strcmp(name, "sort.rank")) *value = d->rank_mode;
-    else if (!strcmp(name, "sort.wgs_per_cu")) *value = d->wgs_per_cu;
     else if (!strcmp(name, "sort.lds_ordered")) *value = d->lds_ordered;
     else if (!strcmp(name, "profile")) *value = d->profile;
     else return fail("unknown parameter '%s'", name);

@@ -37,6 +37,16 @@
 
 #include "radix_kernels.hpp"
 
+#ifndef ADLHIP_WRITE_UNROLL
+#define ADLHIP_WRITE_UNROLL 4
+#endif
+#ifndef ADLHIP_NT_STORES
+#define ADLHIP_NT_STORES 0
+#endif
+#ifndef ADLHIP_NT_LOADS
+#define ADLHIP_NT_LOADS 0
+#endif
+
 namespace adlhip {
 
 constexpr int kChains = 16;          // independent look-back chains per pass (top nibble of the previous digit)
@@ -343,7 +353,13 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(const E* __restrict_
         const E* p = src + (size_t)elem0 + wbase;
         if (valid == (uint32_t)C::TILE) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) e[j] = p[j * 64];
+            for (int j = 0; j < K; ++j) {
+#if ADLHIP_NT_LOADS
+                e[j] = __builtin_nontemporal_load(&p[j * 64]);
+#else
+                e[j] = p[j * 64];
+#endif
+            }
         } else {
             const int rem = (int)valid - (int)wbase;   // element j of this lane's column exists iff j*64 < rem
 #pragma unroll
@@ -437,13 +453,19 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(const E* __restrict_
     ADLHIP_STAMP(tile, 9);
 
     // ---- write-out ---------------------------------------------------------------------------------
-#pragma unroll 4
+#pragma unroll ADLHIP_WRITE_UNROLL
     for (int i = 0; i < K; ++i) {
         if (i * NT < (int)valid - tid) {   // tile position tid + i*NT exists
             const E v = s_elems[tid + i * NT];
             const uint32_t d = digit_of<NBITS>(v, start_bit);
             const uint32_t g = s_goff[d] + (uint32_t)(tid + i * NT);
-            if (g < n) dst[(size_t)g] = v;   // always true for a sound offset (guards a faulted look-back)
+            if (g < n) {   // always true for a sound offset (guards a faulted look-back)
+#if ADLHIP_NT_STORES
+                __builtin_nontemporal_store(v, &dst[(size_t)g]);
+#else
+                dst[(size_t)g] = v;
+#endif
+            }
         }
     }
     ADLHIP_STAMP(tile, 10);

@@ -218,17 +218,20 @@ __device__ __forceinline__ void sort_scatter_tile(const E* __restrict__ src, E* 
 #pragma unroll
     for (int b = lane; b < BINS; b += 64) my_wcnt[b] = 0u;
 
-    // load, wave-striped
+    // load, wave-striped: one 64-bit pointer per tile + constant offsets; the tail predicate compares a
+    // per-lane remainder with constants, so nothing per-element is loop-invariant (the compiler had
+    // hoisted 2K address registers out of the tile loop otherwise)
     E e[K];
-    const uint32_t wbase = (uint32_t)(w * 64 * K + lane);
-    if (valid == (uint32_t)C::TILE) {
+    {
+        const uint32_t wbase = (uint32_t)(w * 64 * K + lane);
+        const E* p = src + (size_t)tile_base + wbase;
+        if (valid == (uint32_t)C::TILE) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) e[j] = src[(size_t)tile_base + wbase + (uint32_t)(j * 64)];
-    } else {
+            for (int j = 0; j < K; ++j) e[j] = p[j * 64];
+        } else {
+            const int rem = (int)valid - (int)wbase;   // element j of this lane's column exists iff j*64 < rem
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const uint32_t idx = wbase + (uint32_t)(j * 64);
-            e[j] = idx < valid ? src[(size_t)tile_base + idx] : ~E(0);
+            for (int j = 0; j < K; ++j) e[j] = (j * 64 < rem) ? p[j * 64] : ~E(0);
         }
     }
 
@@ -242,9 +245,20 @@ __device__ __forceinline__ void sort_scatter_tile(const E* __restrict__ src, E* 
     }
 #endif
     ADLHIP_STAMP(stamp_tile, 1);
-    // rank within the wave
-    uint32_t rnk[K];
-    rank_in_wave<E, NBITS, K, RANK>(e, rnk, my_wcnt, start_bit);
+    // rank within the wave; two 16-bit ranks (< 64*K) per register
+    uint32_t rnk2[(K + 1) / 2];
+    {
+        uint32_t rnk[K];
+        rank_in_wave<E, NBITS, K, RANK>(e, rnk, my_wcnt, start_bit);
+#pragma unroll
+        for (int j = 0; j < K; j += 2) rnk2[j >> 1] = rnk[j] | ((j + 1 < K ? rnk[j + 1] : 0u) << 16);
+    }
+    // opaque from here on: otherwise the 32-bit ranks and the per-element LDS addresses of the ranking
+    // phase stay live across the barriers (+50 VGPRs)
+#pragma unroll
+    for (int j = 0; j < (K + 1) / 2; ++j) asm volatile("" : "+v"(rnk2[j]));
+#pragma unroll
+    for (int j = 0; j < K; ++j) asm volatile("" : "+v"(e[j]));
     ADLHIP_STAMP(stamp_tile, 2);
     __syncthreads();
     ADLHIP_STAMP(stamp_tile, 3);
@@ -275,26 +289,34 @@ __device__ __forceinline__ void sort_scatter_tile(const E* __restrict__ src, E* 
     __syncthreads();
     ADLHIP_STAMP(stamp_tile, 6);
 
-    // local scatter into tile-sorted order
+    // local scatter into tile-sorted order: the LDS reads of the (wave, digit) positions go out CH at a
+    // time ahead of the CH writes that use them (they may alias as far as the compiler knows)
+    {
+        constexpr int CH = K < 8 ? K : 8;
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const uint32_t d = digit_of<NBITS>(e[j], start_bit);
-        s_elems[my_wcnt[d] + rnk[j]] = e[j];
+        for (int j0 = 0; j0 < K; j0 += CH) {
+            uint32_t pos[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) pos[j] = my_wcnt[digit_of<NBITS>(e[j0 + j], start_bit)];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const uint32_t r = (rnk2[(j0 + j) >> 1] >> (16 * ((j0 + j) & 1))) & 0xffffu;
+                s_elems[pos[j] + r] = e[j0 + j];
+            }
+        }
     }
     ADLHIP_STAMP(stamp_tile, 7);
     __syncthreads();
     ADLHIP_STAMP(stamp_tile, 8);
 
     // write-out: consecutive threads -> consecutive tile positions -> contiguous runs per digit
-#pragma unroll
+#pragma unroll 4
     for (int i = 0; i < K; ++i) {
-        const uint32_t p = (uint32_t)(tid + i * NT);
-        if (p < valid) {
-            const E v = s_elems[p];
+        if (i * NT < (int)valid - tid) {   // tile position tid + i*NT exists
+            const E v = s_elems[tid + i * NT];
             const uint32_t d = digit_of<NBITS>(v, start_bit);
-            const uint32_t g = s_goff[d] + p;
-            if (g < n_total) dst[(size_t)g] = v;   // always true for a sound offset; keeps a faulted
-                                                   // look-back (garbage offset) from writing out of bounds
+            const uint32_t g = s_goff[d] + (uint32_t)(tid + i * NT);
+            if (g < n_total) dst[(size_t)g] = v;   // always true for a sound offset
         }
     }
     ADLHIP_STAMP(stamp_tile, 9);

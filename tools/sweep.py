@@ -12,9 +12,12 @@ ap.add_argument("--kind", default="u32")
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--configs", default="")
 ap.add_argument("--verify", action="store_true")
+ap.add_argument("--param", action="append", default=[], help="name=value passed to adlhip_set_param")
 args = ap.parse_args()
 n, K = args.n, args.steps
 d = DeviceUtils.allocate()
+for kv in args.param:
+    k, v = kv.split('='); d.setParam(k, int(v))
 p = Pprims()
 dtype = np.uint32 if args.kind == "u32" else np.uint64
 gen_kind = {"u32": 0, "kv": 1, "u64": 2}[args.kind]
