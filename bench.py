@@ -207,7 +207,8 @@ def main():
         out["event_ms_per_step"] = ev_ms / K
         parallelism = "1 GPU"
         workload = "Key-only RadixSort32, %d uniform-random u32 keys (splitmix64 hi32, seed 123+step), 1xMI355X, in place" % n
-        cfg_extra = {"sort_algo": "onesweep" if algo == 0 else "three-kernel", "digit_bits": digit_bits}
+        algo_name = {0: "onesweep", 1: "three-kernel", -1: "auto (one-sweep at this size)"}.get(algo, str(algo))
+        cfg_extra = {"sort_algo": algo_name, "digit_bits": digit_bits}
     else:
         from oclradixsort_amd.dist import HipBackend, ShardedRadixSort
         be = HipBackend(local_rank)

@@ -169,7 +169,9 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
 /* ---- knobs ---------------------------------------------------------------------------------- */
 
 /* Integer tunables, by name.  Unknown names fail.  Current names:
- *   "sort.algo"        0 = onesweep (one sweep per digit, 16 decoupled look-back chains)  [default]
+ *   "sort.algo"        -1 [default] = by size: n <= 16384 one workgroup does the whole sort in one launch;
+ *                      below ~96 MiB of data the three-kernel pass; above it the one-sweep path
+ *                      0 = onesweep (one sweep per digit, 16 decoupled look-back chains)
  *                      1 = three kernels per pass: count -> table scan -> sort+scatter (the
  *                          reference's pass structure, Pprims.cpp:357-398)
  *   "sort.digit_bits"  8 [default] or 4 (4 = the reference's R32SORT_BITS_PER_PASS, Pprims.h:31)

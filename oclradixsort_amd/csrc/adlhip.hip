@@ -66,7 +66,7 @@ struct adlhip_device {
     hipDeviceProp_t prop;
     uint64_t used_bytes = 0;
     // knobs
-    int sort_algo = 0;        // 0 onesweep, 1 three-kernel pass
+    int sort_algo = -1;       // -1 automatic by size, 0 onesweep, 1 three-kernel pass
     int digit_bits = 8;       // 8 or 4
     int profile = 0;
     int tile_variant = -1;    // index into kVariants; -1 = best known per element size
@@ -478,6 +478,33 @@ int three_kernel_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, c
     return ADLHIP_SUCCESS;
 }
 
+// ---- small inputs: the whole sort in one workgroup ---------------------------------------------------
+constexpr size_t kSmallMax = 16384;
+
+template <typename E, int NT, int K, int RANK>
+int launch_small(adlhip_device* d, E* data, size_t n, const adlhip::SmallPlan& sp)
+{
+    auto kern = adlhip::small_sort_kernel<E, NT, K, RANK>;
+    const size_t lds = sizeof(E) * NT * K + (size_t)(NT / 64) * 256 * 4 + 128;
+    if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
+    return launch(d, sizeof(E) == 4 ? "small_sort_u32" : "small_sort_e64", [&] {
+        hipLaunchKernelGGL(kern, dim3(1), dim3(NT), lds, d->stream, data, (uint32_t)n, sp);
+    });
+}
+
+template <typename E>
+int small_sort(adlhip_device* d, E* data, size_t n, const std::vector<PassPlan>& plan)
+{
+    adlhip::SmallPlan sp;
+    sp.num_passes = (int)plan.size();
+    for (size_t i = 0; i < plan.size(); ++i) {
+        sp.start_bit[i] = (uint8_t)plan[i].start_bit;
+        sp.nbits[i] = (uint8_t)plan[i].nbits;
+    }
+    if (n <= 4096) return d->rank_mode ? launch_small<E, 256, 16, 1>(d, data, n, sp) : launch_small<E, 256, 16, 0>(d, data, n, sp);
+    return d->rank_mode ? launch_small<E, 1024, 16, 1>(d, data, n, sp) : launch_small<E, 1024, 16, 0>(d, data, n, sp);
+}
+
 size_t sort_work_bytes(const adlhip_device* d, int elem_kind, size_t n)
 {
     const size_t a = work_bytes_three_kernel(d, n);
@@ -500,6 +527,11 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
     const size_t need = sort_work_bytes(d, elem_kind, n);
     if (work_bytes < need) return fail("work buffer too small: %zu < %zu", work_bytes, need);
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
+    if (d->sort_algo < 0) {   // automatic choice by size (profiles/r1_ncurve.txt)
+        if (n <= kSmallMax) return small_sort<E>(d, data, n, plan);   // one workgroup, one launch
+        // the one-sweep path has more fixed cost (histogram, tables, status memset) and wins from ~96 MiB of data
+        if (n * sizeof(E) < (size_t(96) << 20)) return three_kernel_sort<E>(d, data, tmp, work, n, plan);
+    }
     // tile status words carry 30-bit counts: beyond 2^30 elements use the table-based pass
     if (d->sort_algo == 1 || n >= (size_t(1) << 30)) return three_kernel_sort<E>(d, data, tmp, work, n, plan);
     return onesweep_sort<E>(d, data, tmp, work, n, plan);
@@ -567,7 +599,7 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         d->lds_ordered = (ok && mism == 0) ? 1 : 0;
         d->rank_mode = d->lds_ordered;
     }
-    if (const char* a = getenv("ADLHIP_SORT_ALGO")) { int v = atoi(a); if (v == 0 || v == 1) d->sort_algo = v; }
+    if (const char* a = getenv("ADLHIP_SORT_ALGO")) { int v = atoi(a); if (v >= -1 && v <= 1) d->sort_algo = v; }
     if (const char* t = getenv("ADLHIP_SORT_TILE")) { int v = atoi(t); if (v >= -1 && v < kNumVariants) d->tile_variant = v; }
     if (const char* r = getenv("ADLHIP_SORT_RANK")) d->rank_mode = (atoi(r) && d->lds_ordered) ? 1 : 0;
     if (const char* b = getenv("ADLHIP_DIGIT_BITS")) d->digit_bits = (atoi(b) == 4) ? 4 : 8;
@@ -881,7 +913,7 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
 {
     if (!d || !name) return fail("null argument");
     if (!strcmp(name, "sort.algo")) {
-        if (value != 0 && value != 1) return fail("sort.algo must be 0 or 1");
+        if (value < -1 || value > 1) return fail("sort.algo must be -1, 0 or 1");
         d->sort_algo = value;
     } else if (!strcmp(name, "sort.digit_bits")) {
         if (value != 4 && value != 8) return fail("sort.digit_bits must be 4 or 8");

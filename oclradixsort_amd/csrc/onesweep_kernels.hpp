@@ -107,26 +107,53 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
         const uint32_t end = (uint32_t)((begin64 + chunk < n) ? begin64 + chunk : n);
         // pass 0: the workgroup's range lies inside ONE input slice (chunk divides slice0)
         const uint32_t chain0 = begin / slice0;
+        auto bin_of = [&](E x, int p) -> uint32_t {
+            const int sb = desc.start_bit[p];
+            const int nb = desc.nbits[p];
+            if (p == 0) return (chain0 << nb) | ((uint32_t)x & ((1u << nb) - 1u));   // pass 0 starts at bit 0
+            // nb + 4 contiguous bits starting at sb - 4: v = digit << 4 | nibble  ->  bin = nibble << nb | digit
+            uint32_t v;
+            if constexpr (sizeof(E) == 8) v = (uint32_t)((uint64_t)x >> (sb - 4));
+            else v = (uint32_t)x >> (sb - 4);
+            v &= (1u << (nb + 4)) - 1u;
+            return ((v & 15u) << nb) | (v >> 4);
+        };
         auto bump = [&](E x) {
             uint32_t off = 0u;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int sb = desc.start_bit[p];
-                const int nb = desc.nbits[p];
-                uint32_t bin;
-                if (p == 0) {
-                    const uint32_t d = (uint32_t)x & ((1u << nb) - 1u);   // pass 0 starts at bit 0
-                    bin = (chain0 << nb) | d;
-                } else {
-                    // nb + 4 contiguous bits starting at sb - 4: v = digit << 4 | nibble
-                    uint32_t v;
-                    if constexpr (sizeof(E) == 8) v = (uint32_t)((uint64_t)x >> (sb - 4));
-                    else v = (uint32_t)x >> (sb - 4);
-                    v &= (1u << (nb + 4)) - 1u;
-                    bin = ((v & 15u) << nb) | (v >> 4);
+                atomicAdd(&hist[off + bin_of(x, p)], 1u);
+                off += joint_bins(desc.nbits[p]);
+            }
+        };
+        // 4 vectors at once.  Per pass: if every element of every active lane falls into one bin (constant /
+        // sorted input) one lane adds the total instead of 64 lanes serialising on one LDS word; the check is
+        // ~1 VALU per atomic it guards.
+        auto bump4 = [&](const auto& a, const auto& b, const auto& c, const auto& d4) {
+            constexpr int V = 16 / (int)sizeof(E);
+            uint32_t off = 0u;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                uint32_t bins[4 * V];
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    bins[4 * k + 0] = bin_of(a.v[k], p);
+                    bins[4 * k + 1] = bin_of(b.v[k], p);
+                    bins[4 * k + 2] = bin_of(c.v[k], p);
+                    bins[4 * k + 3] = bin_of(d4.v[k], p);
                 }
-                atomicAdd(&hist[off + bin], 1u);
-                off += joint_bins(nb);
+                const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)bins[0]);
+                bool same = true;
+#pragma unroll
+                for (int k = 0; k < 4 * V; ++k) same &= bins[k] == b0;
+                if (__all(same)) {
+                    const uint64_t act = __ballot(true);   // the last iteration runs with some lanes off
+                    if (mbcnt64(act) == 0u) atomicAdd(&hist[off + b0], (uint32_t)(4 * V * __popcll(act)));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4 * V; ++k) atomicAdd(&hist[off + bins[k]], 1u);
+                }
+                off += joint_bins(desc.nbits[p]);
             }
         };
         constexpr int VEC = 16 / (int)sizeof(E);
@@ -136,8 +163,7 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
         uint32_t i = (uint32_t)tid;
         for (; i + 3u * kHistNT < nvec; i += 4u * kHistNT) {
             Vec a = vsrc[i], b = vsrc[i + kHistNT], c = vsrc[i + 2 * kHistNT], d4 = vsrc[i + 3 * kHistNT];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) { bump(a.v[k]); bump(b.v[k]); bump(c.v[k]); bump(d4.v[k]); }
+            bump4(a, b, c, d4);
         }
         for (; i < nvec; i += kHistNT) {
             Vec a = vsrc[i];

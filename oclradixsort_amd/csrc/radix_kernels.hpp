@@ -155,10 +155,24 @@ template <typename E, int NBITS, int K, int RANK>
 __device__ __forceinline__ void rank_in_wave(const E (&e)[K], uint32_t (&rnk)[K], uint32_t* my_wcnt, int start_bit)
 {
     if constexpr (RANK == 1) {
+        // 64 lanes on ONE counter serialise in the DS atomic unit (constant / sorted / low-entropy input made
+        // sorts up to 3.5x slower).  One check per wave and tile: if all 64*K elements of this wave share a
+        // digit, their ranks are simply item*64 + lane.  Costs ~1 VALU per element on random data and keeps the
+        // K atomics below back to back.
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)digit_of<NBITS>(e[0], start_bit));
+        bool same = true;
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const uint32_t d = digit_of<NBITS>(e[j], start_bit);
-            rnk[j] = __hip_atomic_fetch_add(&my_wcnt[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int j = 0; j < K; ++j) same &= digit_of<NBITS>(e[j], start_bit) == d0;
+        if (__all(same)) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) rnk[j] = (uint32_t)(j * 64 + lane_id());
+            if (lane_id() == 0) __hip_atomic_store(&my_wcnt[d0], (uint32_t)(64 * K), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint32_t d = digit_of<NBITS>(e[j], start_bit);
+                rnk[j] = __hip_atomic_fetch_add(&my_wcnt[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     } else {
 #pragma unroll
@@ -357,8 +371,28 @@ __global__ __launch_bounds__(NT) void radix_count_kernel(const E* __restrict__ s
         struct alignas(16) Vec { E v[VEC]; };
         auto bump = [&](E x) {
             const uint32_t d = digit_of<NBITS>(x, start_bit);
-            if (NBITS <= 4) atomicAdd(&hist[d * 64 + lane], 1u);
+            if (NBITS <= 4) atomicAdd(&hist[d * 64 + lane], 1u);   // one private column per lane: never collides
             else atomicAdd(&hist[w * BINS + d], 1u);
+        };
+        // 4 vectors at once; if every element of every active lane has the same digit (constant / sorted
+        // input) one lane adds the total instead of 64 lanes serialising on one LDS word
+        auto bump4 = [&](const auto& a, const auto& b, const auto& c, const auto& d4) {
+            constexpr int V = 16 / (int)sizeof(E);
+            if (NBITS > 4) {
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)digit_of<NBITS>(a.v[0], start_bit));
+                bool same = true;
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+                    same &= (digit_of<NBITS>(a.v[k], start_bit) == d0) & (digit_of<NBITS>(b.v[k], start_bit) == d0) &
+                            (digit_of<NBITS>(c.v[k], start_bit) == d0) & (digit_of<NBITS>(d4.v[k], start_bit) == d0);
+                if (__all(same)) {
+                    const uint64_t act = __ballot(true);
+                    if (mbcnt64(act) == 0u) atomicAdd(&hist[w * BINS + d0], (uint32_t)(4 * V * __popcll(act)));
+                    return;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) { bump(a.v[k]); bump(b.v[k]); bump(c.v[k]); bump(d4.v[k]); }
         };
         const uint32_t nvec = (end - begin) / VEC;
         const Vec* vsrc = reinterpret_cast<const Vec*>(src + begin);
@@ -366,8 +400,7 @@ __global__ __launch_bounds__(NT) void radix_count_kernel(const E* __restrict__ s
         // 4 independent 16-byte loads in flight per lane
         for (; i + 3u * NT < nvec; i += 4u * NT) {
             Vec a = vsrc[i], b = vsrc[i + NT], c = vsrc[i + 2 * NT], d4 = vsrc[i + 3 * NT];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) { bump(a.v[k]); bump(b.v[k]); bump(c.v[k]); bump(d4.v[k]); }
+            bump4(a, b, c, d4);
         }
         for (; i < nvec; i += NT) {
             Vec a = vsrc[i];
@@ -443,6 +476,108 @@ __global__ __launch_bounds__(NT) void radix_scatter_kernel(const E* __restrict__
                                                carry += cnt;
                                                return g;
                                            });
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Small inputs (n <= NT*K): the whole LSD sort in ONE workgroup and ONE launch -- all passes run on
+// registers + LDS, the data touches global memory once in and once out.  Replaces the 9-12 dependent
+// launches (~55-90 us of launch latency) the general paths need regardless of n; the reference's Demo
+// sizes 1K..16K land here.
+// ------------------------------------------------------------------------------------------
+struct SmallPlan {
+    int num_passes;
+    uint8_t start_bit[16];
+    uint8_t nbits[16];
+};
+
+template <typename E, int NT, int K, int RANK>
+__global__ __launch_bounds__(NT) void small_sort_kernel(E* __restrict__ data, uint32_t n, SmallPlan plan)
+{
+    constexpr int BINS = 256;
+    constexpr int NW = NT / 64;
+    constexpr int TILE = NT * K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    E* __restrict__ s_elems = reinterpret_cast<E*>(smem);
+    uint32_t* __restrict__ s_wcnt = reinterpret_cast<uint32_t*>(smem + sizeof(E) * TILE);   // [NW][BINS]
+    uint32_t* __restrict__ s_wsum = s_wcnt + NW * BINS;
+
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    uint32_t* my_wcnt = s_wcnt + w * BINS;
+    const uint32_t wbase = (uint32_t)(w * 64 * K + lane);
+
+    // wave-striped load; slots beyond n are padded with all-ones (they rank last and are never stored)
+    E e[K];
+    {
+        const int rem = (int)n - (int)wbase;
+#pragma unroll
+        for (int j = 0; j < K; ++j) e[j] = (j * 64 < rem) ? data[wbase + (uint32_t)(j * 64)] : ~E(0);
+    }
+
+    for (int p = 0; p < plan.num_passes; ++p) {
+        const int sb = plan.start_bit[p];
+        const uint32_t mask = (1u << plan.nbits[p]) - 1u;
+        auto digit = [&](E x) -> uint32_t {
+            if constexpr (sizeof(E) == 8) return (uint32_t)((uint64_t)x >> sb) & mask;
+            else return ((uint32_t)x >> sb) & mask;
+        };
+        // pads (all-ones) have the top digit in every pass and start behind every real element, so they
+        // stay at the end of the tile through all (stable) passes
+#pragma unroll
+        for (int b = lane; b < BINS; b += 64) my_wcnt[b] = 0u;
+        uint32_t rnk[K];
+        if constexpr (RANK == 1) {
+#pragma unroll
+            for (int j = 0; j < K; ++j)   // (n <= 16 Ki: the same-digit serialisation does not matter here)
+                rnk[j] = __hip_atomic_fetch_add(&my_wcnt[digit(e[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint32_t d = digit(e[j]);
+                const uint64_t m = match_digit<8>(d);
+                const uint32_t below = mbcnt64(m);
+                const uint32_t old = __hip_atomic_load(&my_wcnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (below == 0u)
+                    __hip_atomic_fetch_add(&my_wcnt[d], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                rnk[j] = old + below;
+            }
+        }
+        __syncthreads();
+        // thread b (< 256): fold the per-wave counts of digit b, scan over digits, write tile positions
+        uint32_t cnt_b = 0u;
+        uint32_t wc[NW];
+        if (tid < BINS) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                wc[i] = s_wcnt[i * BINS + tid];
+                cnt_b += wc[i];
+            }
+        }
+        const uint32_t toff = block_excl_scan_u32<NT>(cnt_b, s_wsum, nullptr);
+        if (tid < BINS) {
+            uint32_t run = toff;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                s_wcnt[i * BINS + tid] = run;
+                run += wc[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < K; ++j) s_elems[my_wcnt[digit(e[j])] + rnk[j]] = e[j];
+        __syncthreads();
+        // back to registers in wave-striped order = the order the next pass must preserve
+#pragma unroll
+        for (int j = 0; j < K; ++j) e[j] = s_elems[wbase + (uint32_t)(j * 64)];
+        __syncthreads();
+    }
+    {
+        const int rem = (int)n - (int)wbase;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j * 64 < rem) data[wbase + (uint32_t)(j * 64)] = e[j];
     }
 }
 

@@ -18,9 +18,9 @@ from oclradixsort_amd import AdlHipError, Buffer, DeviceUtils, Pprims, Stopwatch
 pytestmark = pytest.mark.gpu
 
 # (sort.algo, sort.digit_bits, sort.tile, sort.rank)
-ALGOS = [(0, 8, -1, 1), (0, 4, -1, 1), (1, 8, -1, 1), (1, 4, -1, 1), (0, 8, -1, 0), (1, 8, 0, 0), (0, 8, 0, 1), (1, 8, 1, 1),
+ALGOS = [(-1, 8, -1, 1), (-1, 4, -1, 0), (0, 8, -1, 1), (0, 4, -1, 1), (1, 8, -1, 1), (1, 4, -1, 1), (0, 8, -1, 0), (1, 8, 0, 0), (0, 8, 0, 1), (1, 8, 1, 1),
          (0, 8, 3, 1), (1, 8, 4, 0), (0, 8, 5, 1), (0, 8, 2, 1), (0, 4, 0, 0)]
-ALGO_IDS = ["onesweep8", "onesweep4", "threekernel8", "threekernel4", "onesweep8-ballot", "threekernel8-256x16-ballot",
+ALGO_IDS = ["auto8", "auto4-ballot", "onesweep8", "onesweep4", "threekernel8", "threekernel4", "onesweep8-ballot", "threekernel8-256x16-ballot",
             "onesweep8-256x16", "threekernel8-512x16", "onesweep8-512x8", "threekernel8-1024x8-ballot",
             "onesweep8-256x32", "onesweep8-1024x16", "onesweep4-256x16-ballot"]
 
@@ -34,7 +34,7 @@ def dev():
 
 @pytest.fixture()
 def pp(dev):
-    set_algo(dev, (0, 8, -1))
+    set_algo(dev, (-1, 8, -1))
     p = Pprims()
     yield p
     p.close()
@@ -139,6 +139,7 @@ def test_bad_arguments_fail_loudly(dev, pp):
             pp.radixSort(dev, b, 1024, bits)     # Pprims.cpp:330: (sortBits & 3) == 0
     with pytest.raises(AdlHipError):
         dev.setParam("sort.algo", 7)
+    assert dev.getParam("sort.algo") in (-1, 0, 1)
     with pytest.raises(AdlHipError):
         dev.setParam("no.such.param", 1)
     b.release()
@@ -380,7 +381,7 @@ def test_stopwatch_and_profiling(dev, pp):
     prof = dev.profile(reset=True)
     dev.toggleProfiling(False)
     assert ms > 0
-    assert any(k.startswith("onesweep_u32") for k in prof), prof
+    assert any(k.startswith(("onesweep_u32", "scatter_u32")) for k in prof), prof
     assert sum(v[1] for v in prof.values()) > 0
     b.release()
 

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Sort time on non-uniform inputs (64Mi u32): sorted, reverse, all-equal, 16 distinct values, low byte only."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oclradixsort_amd import Buffer, DeviceUtils, Pprims, Stopwatch
+n = 1 << 26
+d = DeviceUtils.allocate(); p = Pprims()
+base = Buffer(d, n, np.uint32); work = Buffer(d, n, np.uint32)
+def make(kind):
+    base.generate(n, seed=9)
+    if kind == "uniform": return
+    if kind == "sorted": p.radixSort(d, base, n); return
+    h = None
+    if kind == "all_equal": a = np.full(n, 0x12345678, dtype=np.uint32)
+    elif kind == "16_values": a = (np.arange(n, dtype=np.uint32) * np.uint32(2654435761) >> np.uint32(28)) * np.uint32(0x11111111)
+    elif kind == "low_byte": a = (np.arange(n, dtype=np.uint32) * np.uint32(2654435761)) >> np.uint32(24)
+    elif kind == "reverse":
+        p.radixSort(d, base, n); a = base.toHost()[::-1].copy()
+    base.write(a); DeviceUtils.waitForCompletion(d)
+print("%-12s %s" % ("input", "ms/sort by (algo, rank)"))
+for kind in ("uniform", "sorted", "reverse", "all_equal", "16_values", "low_byte"):
+    make(kind)
+    row = []
+    for algo, rank in ((0, 1), (0, 0), (1, 1), (1, 0)):
+        d.setParam("sort.algo", algo); d.setParam("sort.rank", rank)
+        best = 1e9
+        for t in range(3):
+            work.write(base, n)
+            DeviceUtils.waitForCompletion(d)
+            sw = Stopwatch(d); sw.start(); p.radixSort(d, work, n); sw.stop()
+            best = min(best, sw.getMs())
+        row.append("a%d/r%d %.3f" % (algo, rank, best))
+    print("%-12s %s" % (kind, "   ".join(row)), flush=True)
+base.release(); work.release(); p.close(); DeviceUtils.deallocate(d)

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Throughput-vs-n curve (the shape of Fig. 5 of the reference's paper): u32 keys, n = 2^10 .. 2^28."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oclradixsort_amd import Buffer, DeviceUtils, Pprims, Stopwatch
+d = DeviceUtils.allocate(); p = Pprims()
+print("%12s %10s %10s %10s" % ("n", "us/sort", "Gkeys/s", "algo"))
+for lg in range(10, 29):
+    n = 1 << lg
+    reps = max(3, min(200, (1 << 27) // n))
+    bufs = [Buffer(d, n, np.uint32) for _ in range(min(reps, 8))]
+    for algo in (0, 1):
+        d.setParam("sort.algo", algo)
+        best = 1e9
+        for trial in range(3):
+            for i, b in enumerate(bufs): b.generate(n, seed=trial * 100 + i)
+            DeviceUtils.waitForCompletion(d)
+            sw = Stopwatch(d); sw.start()
+            for r in range(reps): p.radixSort(d, bufs[r % len(bufs)], n)
+            sw.stop()
+            best = min(best, sw.getMs() / reps)
+        print("%12d %10.1f %10.2f %10s" % (n, best * 1e3, n / best / 1e6, "onesweep" if algo == 0 else "3-kernel"), flush=True)
+    for b in bufs: b.release()
+p.close(); DeviceUtils.deallocate(d)
