@@ -213,14 +213,16 @@ Geometry geometry(const adlhip_device* d, size_t n, uint32_t tile)
 // "sort.tile" = -1 (default): the measured best per element size on MI355X
 //   4-byte elements: 512 x 32 (16 Ki keys, 73 KiB of LDS, two workgroups per CU)
 //   8-byte elements: 1024 x 16 (16 Ki elements, 145 KiB of LDS, one workgroup per CU)
-int effective_variant(const adlhip_device* d, size_t elem_bytes)
+//   up to 8 MiB of data: 256 x 16 (4 Ki elements) so that there are enough tiles to occupy 256 CUs
+int effective_variant(const adlhip_device* d, size_t elem_bytes, size_t n)
 {
     if (d->tile_variant >= 0) return d->tile_variant;
+    if (n * elem_bytes <= (size_t(8) << 20)) return 0;
     return elem_bytes == 4 ? 6 : 2;
 }
-uint32_t current_tile(const adlhip_device* d, size_t elem_bytes)
+uint32_t current_tile(const adlhip_device* d, size_t elem_bytes, size_t n)
 {
-    const TileVariant v = kVariants[effective_variant(d, elem_bytes)];
+    const TileVariant v = kVariants[effective_variant(d, elem_bytes, n)];
     return (uint32_t)(v.nt * v.k);
 }
 
@@ -279,7 +281,7 @@ int launch_scatter(adlhip_device* d, const E* src, E* dst, const uint32_t* table
 }
 
 #define ADLHIP_DISPATCH_TILE(FN, E, NBITS, ...)                                                     \
-    switch (effective_variant(d, sizeof(E)) * 2 + (d->rank_mode ? 1 : 0)) {                                         \
+    switch (effective_variant(d, sizeof(E), n) * 2 + (d->rank_mode ? 1 : 0)) {                                         \
     case 0: return FN<E, NBITS, 256, 16, 0>(__VA_ARGS__);                                           \
     case 1: return FN<E, NBITS, 256, 16, 1>(__VA_ARGS__);                                           \
     case 2: return FN<E, NBITS, 512, 16, 0>(__VA_ARGS__);                                           \
@@ -308,7 +310,7 @@ template <typename E, int NBITS>
 int three_kernel_pass(adlhip_device* d, const E* src, E* dst, void* work, size_t n, int start_bit)
 {
     constexpr int kCountNT = 256;
-    const Geometry g = geometry(d, n, current_tile(d, sizeof(E)));
+    const Geometry g = geometry(d, n, current_tile(d, sizeof(E), n));
     uint32_t* table = reinterpret_cast<uint32_t*>(work);
     uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + table_bytes(d, n, kMinTile));
     const uint32_t elems_per_wg = g.tiles_per_wg * g.tile;
@@ -391,7 +393,7 @@ template <typename E>
 int onesweep_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, const std::vector<PassPlan>& plan)
 {
     const int P = (int)plan.size();
-    const uint32_t tile = current_tile(d, sizeof(E));
+    const uint32_t tile = current_tile(d, sizeof(E), n);
     // offsets come from the worst-case layout the caller sized the buffer with
     const OnesweepLayout L = onesweep_layout(d, n, (int)(sizeof(E) == 4 ? 8 : 16), kMinTile);
     char* wb = reinterpret_cast<char*>(work);

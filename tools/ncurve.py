@@ -10,7 +10,7 @@ for lg in range(10, 29):
     n = 1 << lg
     reps = max(3, min(200, (1 << 27) // n))
     bufs = [Buffer(d, n, np.uint32) for _ in range(min(reps, 8))]
-    for algo in (0, 1):
+    for algo in (-1, 0, 1):
         d.setParam("sort.algo", algo)
         best = 1e9
         for trial in range(3):
@@ -20,6 +20,6 @@ for lg in range(10, 29):
             for r in range(reps): p.radixSort(d, bufs[r % len(bufs)], n)
             sw.stop()
             best = min(best, sw.getMs() / reps)
-        print("%12d %10.1f %10.2f %10s" % (n, best * 1e3, n / best / 1e6, "onesweep" if algo == 0 else "3-kernel"), flush=True)
+        print("%12d %10.1f %10.2f %10s" % (n, best * 1e3, n / best / 1e6, {-1: "auto", 0: "onesweep", 1: "3-kernel"}[algo]), flush=True)
     for b in bufs: b.release()
 p.close(); DeviceUtils.deallocate(d)
