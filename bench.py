@@ -97,12 +97,19 @@ def main():
     K, W = args.steps, args.warmup
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
     out = {}
-    if world == 1:
+    # ADLHIP_BENCH_FORCE_DIST=1: take the multi-GPU code path (partition + RCCL collectives) even with one rank,
+    # to exercise it on a 1-GPU box; the number it prints is NOT the N = 1 benchmark
+    force_dist = os.environ.get("ADLHIP_BENCH_FORCE_DIST") == "1"
+    if force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    if world == 1 and not force_dist:
         d = DeviceUtils.allocate(cfg=Config(local_rank))
         if args.algo is not None:
             d.setParam("sort.algo", args.algo)
@@ -228,11 +235,11 @@ def main():
         torch.cuda.synchronize()
         res = None
         for i in range(W):
-            res = sorter.sort(inputs[i])
+            res = sorter.sort(inputs[i], force_exchange=force_dist)
         barrier()
         t0 = time.perf_counter()
         for i in range(W, W + K):
-            res = sorter.sort(inputs[i])
+            res = sorter.sort(inputs[i], force_exchange=force_dist)
         barrier()
         wall = time.perf_counter() - t0
         verified = None
@@ -269,7 +276,7 @@ def main():
         cfg_extra = {}
 
     # max over ranks
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -297,10 +304,21 @@ def main():
         line.update(out)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], _ = cpu_baseline(n)
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
 
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL prints a version banner through C stdio, which is flushed only at exit: push it out first so
+        # that the JSON line is the LAST line on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -98,11 +98,12 @@ class ShardedRadixSort:
             raise ValueError("at most 256 ranks")
         self.last_splits = None
 
-    def sort(self, keys):
+    def sort(self, keys, force_exchange=False):
         """keys: this rank's shard.  Returns this rank's slice of the globally sorted sequence
-        (all keys whose top log2(world) bits equal the rank, ascending)."""
+        (all keys whose top log2(world) bits equal the rank, ascending).  force_exchange runs the
+        partition + collectives even with one rank (used to exercise the code path on a 1-GPU box)."""
         G = self.world
-        if G == 1:
+        if G == 1 and not (force_exchange and dist.is_initialized()):
             return self.backend.local_sort(keys)
         part, counts = self.backend.partition_msb(keys, G)
         # one collective for all split sizes: row r of the matrix = rank r's send counts
