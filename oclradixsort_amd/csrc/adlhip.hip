@@ -167,7 +167,8 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // ---- sort configuration -------------------------------------------------------------------
 
 // Tile geometry variants (threads per workgroup NT x elements per thread K), selectable at run time
-// through "sort.tile".  Scratch is always sized for the smallest tile (kMinTile) so that changing the
+// through "sort.tile".  The small digit table of the three-kernel pass is sized for the smallest tile (kMinTile);
+// the status rows of the one-sweep pass are sized for the CURRENT knobs (a sort call re-checks the size, so changing the
 // variant never invalidates a caller's work buffer.
 struct TileVariant {
     int nt, k;
@@ -353,6 +354,9 @@ uint32_t hist_wgs_for(const adlhip_device* d, size_t n)
 // status rows of one pass: one per tile; every chain may add one partial tile
 size_t status_rows(size_t n, uint32_t tile) { return (n + tile - 1) / tile + adlhip::kChains + 1; }
 
+// most passes a sort of `key_bits`-bit keys can need with the current digit width (8,8,8,4 style plans included)
+int max_passes_for(const adlhip_device* d, int key_bits) { return d->digit_bits == 8 ? (key_bits + 7) / 8 : key_bits / 4; }
+
 OnesweepLayout onesweep_layout(const adlhip_device* d, size_t n, int max_passes, uint32_t tile)
 {
     OnesweepLayout L;
@@ -395,7 +399,7 @@ int onesweep_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, const
     const int P = (int)plan.size();
     const uint32_t tile = current_tile(d, sizeof(E), n);
     // offsets come from the worst-case layout the caller sized the buffer with
-    const OnesweepLayout L = onesweep_layout(d, n, (int)(sizeof(E) == 4 ? 8 : 16), kMinTile);
+    const OnesweepLayout L = onesweep_layout(d, n, max_passes_for(d, sizeof(E) == 4 ? 32 : 64), tile);
     char* wb = reinterpret_cast<char*>(work);
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(wb + L.off_ctrl);
     adlhip::PassTable* tables = reinterpret_cast<adlhip::PassTable*>(wb + L.off_tables);
@@ -510,7 +514,8 @@ int small_sort(adlhip_device* d, E* data, size_t n, const std::vector<PassPlan>&
 size_t sort_work_bytes(const adlhip_device* d, int elem_kind, size_t n)
 {
     const size_t a = work_bytes_three_kernel(d, n);
-    const size_t b = onesweep_layout(d, n, elem_kind == ADLHIP_ELEM_U32 ? 8 : 16, kMinTile).total;   // as onesweep_sort<E>()
+    const size_t esz = elem_kind == ADLHIP_ELEM_U32 ? 4 : 8;
+    const size_t b = onesweep_layout(d, n, max_passes_for(d, esz == 4 ? 32 : 64), current_tile(d, esz, n)).total;   // as onesweep_sort<E>()
     return std::max(a, b);
 }
 

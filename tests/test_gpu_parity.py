@@ -438,3 +438,56 @@ def test_generated_keys_match_the_oracle_generator(dev):
         b.generate(n, seed=123, firstIndex=77, kind=kind)
         assert np.array_equal(b.toHost(), want), kind
         b.release()
+
+
+def test_abi_argument_validation(dev):
+    """The C ABI refuses bad buffers loudly instead of launching kernels on them."""
+    import ctypes
+    from oclradixsort_amd import _lib
+    lib = _lib.load()
+    n = 1 << 20
+    keys = Buffer(dev, n + 4, np.uint32)
+    tmp = Buffer(dev, n + 4, np.uint32)
+    tb, wb = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.adlhip_radix_sort_scratch_bytes(dev._h, 0, n, ctypes.byref(tb), ctypes.byref(wb)) == 0
+    work = Buffer(dev, wb.value, np.uint8)
+    ok = lambda rc: rc == 0
+    # too small a work buffer
+    assert not ok(lib.adlhip_radix_sort_u32(dev._h, keys.ptr(), tmp.ptr(), work.ptr(), wb.value - 1, n, 32))
+    assert b"work buffer too small" in lib.adlhip_last_error()
+    # null buffers
+    assert not ok(lib.adlhip_radix_sort_u32(dev._h, keys.ptr(), None, work.ptr(), wb.value, n, 32))
+    assert not ok(lib.adlhip_radix_sort_u32(dev._h, None, tmp.ptr(), work.ptr(), wb.value, n, 32))
+    # misaligned data pointer (element offset 1 = 4 bytes)
+    assert not ok(lib.adlhip_radix_sort_u32(dev._h, keys.ptr(1), tmp.ptr(), work.ptr(), wb.value, n, 32))
+    assert b"16-byte aligned" in lib.adlhip_last_error()
+    # bad element kind / bucket count
+    assert not ok(lib.adlhip_radix_sort_scratch_bytes(dev._h, 7, n, ctypes.byref(tb), ctypes.byref(wb)))
+    cnt = Buffer(dev, 256, np.uint32)
+    assert not ok(lib.adlhip_partition_msb_u32(dev._h, keys.ptr(), tmp.ptr(), cnt.ptr(), work.ptr(), work.getSize(), n, 3))
+    # and the good call still works afterwards
+    k = oracle.keys_u32(n, 5)
+    keys.write(k, n)
+    assert ok(lib.adlhip_radix_sort_u32(dev._h, keys.ptr(), tmp.ptr(), work.ptr(), work.getSize(), n, 32))
+    assert np.array_equal(keys.toHost(n), oracle.sort_u32(k))
+    for b in (keys, tmp, work, cnt):
+        b.release()
+
+
+def test_two_pprims_and_two_devices_do_not_interfere(dev):
+    d2 = DeviceUtils.allocate()
+    p1, p2 = Pprims(), Pprims()
+    try:
+        n = 500009
+        k1, k2 = oracle.keys_u32(n, 1), oracle.keys_u32(n, 2)
+        b1, b2 = Buffer(dev, n, np.uint32), Buffer(d2, n, np.uint32)
+        b1.write(k1); b2.write(k2)
+        for _ in range(3):           # interleaved, unsynchronised
+            p1.radixSort(dev, b1, n)
+            p2.radixSort(d2, b2, n)
+        assert np.array_equal(b1.toHost(), oracle.sort_u32(k1))
+        assert np.array_equal(b2.toHost(), oracle.sort_u32(k2))
+        b1.release(); b2.release()
+    finally:
+        p1.close(); p2.close()
+        DeviceUtils.deallocate(d2)
