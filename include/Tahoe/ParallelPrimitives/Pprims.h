@@ -44,6 +44,11 @@ public:
 
     void radixSort(const adl::Device* device, const adl::Buffer<u64>& inout, int n, int sortBits = 64);
 
+    // separate key and value buffers (the layout of the reference's never-launched SoA kernel,
+    // RadixSortKeyValueKernels.cl:354-509): ascending by key, stable, values follow their keys
+    void radixSort(const adl::Device* device, const adl::Buffer<u32>& keys, const adl::Buffer<u32>& values, int n,
+                   int sortBits = 32);
+
 private:
     // device scratch owned by the object and grown lazily (reference: m_u32WorkBuffer[0] = ping-pong data,
     // m_u32WorkBuffer[1] = histogram table; Pprims.h:44-45)

@@ -113,6 +113,7 @@ int adlhip_unmap(adlhip_device* dev, void* dptr, void* hptr, size_t bytes);
 #define ADLHIP_ELEM_U32  0 /* Buffer<u32>   : Pprims::radixSort(..., Buffer<u32>&, ...)   Pprims.h:41 */
 #define ADLHIP_ELEM_KV32 1 /* Buffer<uint2> : {x = key, y = value}                         Pprims.h:38 */
 #define ADLHIP_ELEM_U64  2 /* 64-bit keys (BASELINE config #5; no reference API)                       */
+#define ADLHIP_ELEM_SOA32 3 /* separate u32 key and u32 value arrays (*tmp_bytes is per array)           */
 
 /* Scratch the caller must own, replacing Pprims' m_u32WorkBuffer[0] (ping-pong copy of the data,
  * Pprims.cpp:226-232, :332) and m_u32WorkBuffer[1] (histogram table, :229-230, :333-337).
@@ -135,6 +136,15 @@ int adlhip_radix_sort_u32(adlhip_device* dev, uint32_t* d_keys_inout, uint32_t* 
  * (Tahoe/Math/Math.h:175-188 == SortData, Tahoe/Algorithm/Sort/RadixSort.h:10-27); stable. */
 int adlhip_radix_sort_kv32(adlhip_device* dev, void* d_pairs_inout, void* d_tmp,
                            void* d_work, size_t work_bytes, size_t n, int sort_bits);
+
+/* Key-value sort on SEPARATE key and value arrays (structure of arrays): the layout of the reference's
+ * never-launched SortAndScatterKernel(gSrc, gSrcVal, ...) (RadixSortKeyValueKernels.cl:354-509).
+ * Same contract as adlhip_radix_sort_kv32: ascending by the low sort_bits key bits, stable; values follow
+ * their keys.  d_tmp_keys / d_tmp_vals: n u32 each (adlhip_radix_sort_scratch_bytes with ADLHIP_ELEM_SOA32).
+ * The histogram / count kernels read the key array only (half the bytes of the AoS layout). */
+int adlhip_radix_sort_soa32(adlhip_device* dev, uint32_t* d_keys_inout, uint32_t* d_vals_inout,
+                            uint32_t* d_tmp_keys, uint32_t* d_tmp_vals, void* d_work, size_t work_bytes,
+                            size_t n, int sort_bits);
 
 /* 64-bit keys, ascending; sort_bits multiple of 4 in [4,64]. */
 int adlhip_radix_sort_u64(adlhip_device* dev, uint64_t* d_keys_inout, uint64_t* d_tmp,
@@ -202,6 +212,10 @@ int adlhip_event_destroy(adlhip_device* dev, adlhip_event* ev);
 int adlhip_profile_reset(adlhip_device* dev);
 int adlhip_profile_count(adlhip_device* dev);
 int adlhip_profile_get(adlhip_device* dev, int i, char name_out[64], uint64_t* launches, double* total_ms);
+/* Append the table as CSV rows "kernel",launches,total_ms,avg_ms to `path` (header written when the file is
+ * new) -- the reference appends a row per launch to ProfileCL.<device>.<driver>.csv
+ * (Adl/CL/AdlKernelUtilsCL.inl:664-677); here the rows are per kernel, folded since the last reset. */
+int adlhip_profile_write_csv(adlhip_device* dev, const char* path);
 
 /* ---- bandwidth probes (diagnostics for bench.py: empirical HBM ceilings) ---------------------- */
 int adlhip_probe_copy(adlhip_device* dev, void* d_dst, const void* d_src, size_t bytes);

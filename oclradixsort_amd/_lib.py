@@ -57,6 +57,7 @@ SIGNATURES = {
     "adlhip_radix_sort_scratch_bytes": (_I, [_VP, _I, _SZ, c_size_p, c_size_p]),
     "adlhip_radix_sort_u32": (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
     "adlhip_radix_sort_kv32": (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
+    "adlhip_radix_sort_soa32": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
     "adlhip_radix_sort_u64": (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
     "adlhip_scan_scratch_bytes": (_I, [_VP, _SZ, c_size_p]),
     "adlhip_exclusive_scan_u32": (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _VP]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "adlhip_profile_count": (_I, [_VP]),
     "adlhip_profile_get": (_I, [_VP, _I, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64),
                                 ctypes.POINTER(ctypes.c_double)]),
+    "adlhip_profile_write_csv": (_I, [_VP, ctypes.c_char_p]),
     "adlhip_probe_copy": (_I, [_VP, _VP, _VP, _SZ]),
     "adlhip_probe_read": (_I, [_VP, _VP, _SZ, _VP]),
     "adlhip_version": (ctypes.c_char_p, []),

@@ -88,6 +88,10 @@ class Device:
             check(lib.adlhip_profile_reset(self._h), "profile_reset")
         return out
 
+    def writeProfileCsv(self, path):
+        """Append the per-kernel timing table as CSV (the reference's ProfileCL.*.csv hook)."""
+        check(_lib.load().adlhip_profile_write_csv(self._h, path.encode()), "adlhip_profile_write_csv")
+
     @property
     def stream(self):
         return _lib.load().adlhip_stream(self._h)

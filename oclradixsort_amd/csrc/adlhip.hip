@@ -260,64 +260,130 @@ const char* intern(const std::string& s)
     return it->second->c_str();
 }
 
-template <typename E, int NBITS>
+// ---- what a sort ping-pongs between ------------------------------------------------------------------
+// AosBuf<E>: one array of E.  SoaBuf: u32 keys + u32 values in separate arrays (pairs travel through the
+// kernels as u64 {key low, value high}; histogram / count kernels read the key array only).
+template <typename E>
+struct AosBuf {
+    typedef adlhip::AosIO<E> IO;
+    typedef E key_t;
+    static constexpr size_t kElemBytes = sizeof(E);
+    static constexpr bool kSoa = false;
+    E* p;
+    const key_t* keys() const { return p; }
+    bool same(const AosBuf& o) const { return p == o.p; }
+    static IO io(const AosBuf& src, const AosBuf& dst) { return IO{src.p, dst.p}; }
+    int copy_from(const AosBuf& src, size_t n, hipStream_t st) const
+    {
+        HIPCHK(hipMemcpyAsync(p, src.p, n * sizeof(E), hipMemcpyDeviceToDevice, st));
+        return ADLHIP_SUCCESS;
+    }
+    static const char* tag() { return sizeof(E) == 4 ? "_u32" : "_e64"; }
+};
+struct SoaBuf {
+    typedef adlhip::SoaIO IO;
+    typedef uint32_t key_t;
+    static constexpr size_t kElemBytes = 8;
+    static constexpr bool kSoa = true;
+    uint32_t* k;
+    uint32_t* v;
+    const key_t* keys() const { return k; }
+    bool same(const SoaBuf& o) const { return k == o.k; }
+    static IO io(const SoaBuf& src, const SoaBuf& dst) { return IO{src.k, src.v, dst.k, dst.v}; }
+    int copy_from(const SoaBuf& src, size_t n, hipStream_t st) const
+    {
+        HIPCHK(hipMemcpyAsync(k, src.k, n * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(v, src.v, n * 4, hipMemcpyDeviceToDevice, st));
+        return ADLHIP_SUCCESS;
+    }
+    static const char* tag() { return "_soa"; }
+};
+
+template <typename Buf, int NBITS>
 const char* kernel_name(const char* stem)
 {
-    return intern(std::string(stem) + (sizeof(E) == 4 ? "_u32" : "_e64") + (NBITS == 8 ? "_8b" : "_4b"));
+    return intern(std::string(stem) + Buf::tag() + (NBITS == 8 ? "_8b" : "_4b"));
 }
+
+// tile variant: SoA pairs are instantiated for two geometries only (256x16 for small inputs, 1024x16 otherwise)
+template <typename Buf>
+int buf_variant(const adlhip_device* d, size_t n)
+{
+    const int v = effective_variant(d, Buf::kElemBytes, n);
+    if (Buf::kSoa) return v == 0 ? 0 : 2;
+    return v;
+}
+template <typename Buf>
+uint32_t buf_tile(const adlhip_device* d, size_t n)
+{
+    const TileVariant v = kVariants[buf_variant<Buf>(d, n)];
+    return (uint32_t)(v.nt * v.k);
+}
+
+#define ADLHIP_DISPATCH_TILE(FN, Buf, NBITS, ...)                                                     \
+    if (Buf::kSoa) {                                                                                  \
+        switch (buf_variant<Buf>(d, n) * 2 + (d->rank_mode ? 1 : 0)) {                                \
+        case 0: return FN<Buf, NBITS, 256, 16, 0>(__VA_ARGS__);                                       \
+        case 1: return FN<Buf, NBITS, 256, 16, 1>(__VA_ARGS__);                                       \
+        case 4: return FN<Buf, NBITS, 1024, 16, 0>(__VA_ARGS__);                                      \
+        default: return FN<Buf, NBITS, 1024, 16, 1>(__VA_ARGS__);                                     \
+        }                                                                                             \
+    }                                                                                                 \
+    switch (buf_variant<Buf>(d, n) * 2 + (d->rank_mode ? 1 : 0)) {                                    \
+    case 0: return FN<Buf, NBITS, 256, 16, 0>(__VA_ARGS__);                                           \
+    case 1: return FN<Buf, NBITS, 256, 16, 1>(__VA_ARGS__);                                           \
+    case 2: return FN<Buf, NBITS, 512, 16, 0>(__VA_ARGS__);                                           \
+    case 3: return FN<Buf, NBITS, 512, 16, 1>(__VA_ARGS__);                                           \
+    case 4: return FN<Buf, NBITS, 1024, 16, 0>(__VA_ARGS__);                                          \
+    case 5: return FN<Buf, NBITS, 1024, 16, 1>(__VA_ARGS__);                                          \
+    case 6: return FN<Buf, NBITS, 512, 8, 0>(__VA_ARGS__);                                            \
+    case 7: return FN<Buf, NBITS, 512, 8, 1>(__VA_ARGS__);                                            \
+    case 8: return FN<Buf, NBITS, 1024, 8, 0>(__VA_ARGS__);                                           \
+    case 9: return FN<Buf, NBITS, 1024, 8, 1>(__VA_ARGS__);                                           \
+    case 10: return FN<Buf, NBITS, 256, 32, 0>(__VA_ARGS__);                                          \
+    case 11: return FN<Buf, NBITS, 256, 32, 1>(__VA_ARGS__);                                          \
+    case 12: return FN<Buf, NBITS, 512, 32, 0>(__VA_ARGS__);                                          \
+    case 13: return FN<Buf, NBITS, 512, 32, 1>(__VA_ARGS__);                                          \
+    default: return fail("bad tile variant %d", d->tile_variant);                                     \
+    }
 
 // ---- three-kernel pass: count -> table scan -> sort+scatter --------------------------------------
 
-template <typename E, int NBITS, int NT, int K, int RANK>
-int launch_scatter(adlhip_device* d, const E* src, E* dst, const uint32_t* table, const uint32_t* totals, size_t n,
-                   const Geometry& g, int start_bit)
+template <typename Buf, int NBITS, int NT, int K, int RANK>
+int launch_scatter(adlhip_device* d, const Buf& src, const Buf& dst, const uint32_t* table, const uint32_t* totals,
+                   size_t n, const Geometry& g, int start_bit)
 {
-    using C = adlhip::TileCfg<E, NBITS, NT, K>;
-    auto kern = adlhip::radix_scatter_kernel<E, NBITS, NT, K, RANK>;
+    if (Buf::kSoa && !((NT == 256 && K == 16) || (NT == 1024 && K == 16))) return fail("internal: SoA tile");
+    typedef typename Buf::IO IO;
+    using C = adlhip::TileCfg<typename IO::elem_t, NBITS, NT, K>;
+    auto kern = adlhip::radix_scatter_kernel<IO, NBITS, NT, K, RANK>;
     if (ensure_lds(kern, C::LDS_BYTES)) return ADLHIP_FAILURE;
-    return launch(d, kernel_name<E, NBITS>("scatter"), [&] {
-        hipLaunchKernelGGL(kern, dim3(g.n_wgs), dim3(NT), C::LDS_BYTES, d->stream, src, dst, table, totals, (uint32_t)n,
+    const IO io = Buf::io(src, dst);
+    return launch(d, kernel_name<Buf, NBITS>("scatter"), [&] {
+        hipLaunchKernelGGL(kern, dim3(g.n_wgs), dim3(NT), C::LDS_BYTES, d->stream, io, table, totals, (uint32_t)n,
                            (int)g.n_wgs, start_bit, g.tiles_per_wg, g.num_tiles);
     });
 }
 
-#define ADLHIP_DISPATCH_TILE(FN, E, NBITS, ...)                                                     \
-    switch (effective_variant(d, sizeof(E), n) * 2 + (d->rank_mode ? 1 : 0)) {                                         \
-    case 0: return FN<E, NBITS, 256, 16, 0>(__VA_ARGS__);                                           \
-    case 1: return FN<E, NBITS, 256, 16, 1>(__VA_ARGS__);                                           \
-    case 2: return FN<E, NBITS, 512, 16, 0>(__VA_ARGS__);                                           \
-    case 3: return FN<E, NBITS, 512, 16, 1>(__VA_ARGS__);                                           \
-    case 4: return FN<E, NBITS, 1024, 16, 0>(__VA_ARGS__);                                          \
-    case 5: return FN<E, NBITS, 1024, 16, 1>(__VA_ARGS__);                                          \
-    case 6: return FN<E, NBITS, 512, 8, 0>(__VA_ARGS__);                                            \
-    case 7: return FN<E, NBITS, 512, 8, 1>(__VA_ARGS__);                                            \
-    case 8: return FN<E, NBITS, 1024, 8, 0>(__VA_ARGS__);                                           \
-    case 9: return FN<E, NBITS, 1024, 8, 1>(__VA_ARGS__);                                           \
-    case 10: return FN<E, NBITS, 256, 32, 0>(__VA_ARGS__);                                          \
-    case 11: return FN<E, NBITS, 256, 32, 1>(__VA_ARGS__);                                          \
-    case 12: return FN<E, NBITS, 512, 32, 0>(__VA_ARGS__);                                          \
-    case 13: return FN<E, NBITS, 512, 32, 1>(__VA_ARGS__);                                          \
-    default: return fail("bad tile variant %d", d->tile_variant);                                   \
-    }
-
-template <typename E, int NBITS>
-int dispatch_scatter(adlhip_device* d, const E* src, E* dst, const uint32_t* table, const uint32_t* totals, size_t n,
-                     const Geometry& g, int start_bit)
+template <typename Buf, int NBITS>
+int dispatch_scatter(adlhip_device* d, const Buf& src, const Buf& dst, const uint32_t* table, const uint32_t* totals,
+                     size_t n, const Geometry& g, int start_bit)
 {
-    ADLHIP_DISPATCH_TILE(launch_scatter, E, NBITS, d, src, dst, table, totals, n, g, start_bit)
+    ADLHIP_DISPATCH_TILE(launch_scatter, Buf, NBITS, d, src, dst, table, totals, n, g, start_bit)
 }
 
-template <typename E, int NBITS>
-int three_kernel_pass(adlhip_device* d, const E* src, E* dst, void* work, size_t n, int start_bit)
+template <typename Buf, int NBITS>
+int three_kernel_pass(adlhip_device* d, const Buf& src, const Buf& dst, void* work, size_t n, int start_bit)
 {
+    typedef typename Buf::key_t key_t;
     constexpr int kCountNT = 256;
-    const Geometry g = geometry(d, n, current_tile(d, sizeof(E), n));
+    const Geometry g = geometry(d, n, buf_tile<Buf>(d, n));
     uint32_t* table = reinterpret_cast<uint32_t*>(work);
     uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + table_bytes(d, n, kMinTile));
     const uint32_t elems_per_wg = g.tiles_per_wg * g.tile;
-    int rc = launch(d, kernel_name<E, NBITS>("count"), [&] {
-        hipLaunchKernelGGL((adlhip::radix_count_kernel<E, NBITS, kCountNT>), dim3(g.n_wgs), dim3(kCountNT), 0, d->stream,
-                           src, table, (uint32_t)n, (int)g.n_wgs, start_bit, elems_per_wg);
+    int rc = launch(d, kernel_name<Buf, NBITS>("count"), [&] {
+        hipLaunchKernelGGL((adlhip::radix_count_kernel<key_t, NBITS, kCountNT>), dim3(g.n_wgs), dim3(kCountNT), 0, d->stream,
+                           src.keys(), table, (uint32_t)n, (int)g.n_wgs, start_bit, elems_per_wg);
     });
     if (rc) return rc;
     rc = launch(d, "scan_table", [&] {
@@ -325,7 +391,7 @@ int three_kernel_pass(adlhip_device* d, const E* src, E* dst, void* work, size_t
                            totals, (int)g.n_wgs);
     });
     if (rc) return rc;
-    return dispatch_scatter<E, NBITS>(d, src, dst, table, totals, n, g, start_bit);
+    return dispatch_scatter<Buf, NBITS>(d, src, dst, table, totals, n, g, start_bit);
 }
 
 // ---- onesweep --------------------------------------------------------------------------------
@@ -370,36 +436,39 @@ OnesweepLayout onesweep_layout(const adlhip_device* d, size_t n, int max_passes,
     return L;
 }
 
-template <typename E, int NBITS, int NT, int K, int RANK>
-int launch_onesweep(adlhip_device* d, const E* src, E* dst, const adlhip::PassTable* table, uint32_t* status,
+template <typename Buf, int NBITS, int NT, int K, int RANK>
+int launch_onesweep(adlhip_device* d, const Buf& src, const Buf& dst, const adlhip::PassTable* table, uint32_t* status,
                     uint32_t* tickets, size_t n, int start_bit)
 {
-    using C = adlhip::TileCfg<E, NBITS, NT, K>;
-    auto kern = adlhip::onesweep_chain_kernel<E, NBITS, NT, K, RANK>;
+    if (Buf::kSoa && !((NT == 256 && K == 16) || (NT == 1024 && K == 16))) return fail("internal: SoA tile");
+    typedef typename Buf::IO IO;
+    using C = adlhip::TileCfg<typename IO::elem_t, NBITS, NT, K>;
+    auto kern = adlhip::onesweep_chain_kernel<IO, NBITS, NT, K, RANK>;
     if (ensure_lds(kern, C::LDS_BYTES)) return ADLHIP_FAILURE;
     const size_t rows = status_rows(n, (uint32_t)C::TILE);
     const uint32_t grid = (uint32_t)((n + C::TILE - 1) / C::TILE) + adlhip::kChains;   // upper bound on the tile count
     const uint32_t status_bytes = (uint32_t)(rows * C::BINS * 4u);
-    return launch(d, kernel_name<E, NBITS>("onesweep"), [&] {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), C::LDS_BYTES, d->stream, src, dst, table, status, status_bytes,
-                           tickets, d->d_fault, (uint32_t)n, start_bit);
+    const IO io = Buf::io(src, dst);
+    return launch(d, kernel_name<Buf, NBITS>("onesweep"), [&] {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), C::LDS_BYTES, d->stream, io, table, status, status_bytes, tickets,
+                           d->d_fault, (uint32_t)n, start_bit);
     });
 }
 
-template <typename E, int NBITS>
-int dispatch_onesweep(adlhip_device* d, const E* src, E* dst, const adlhip::PassTable* table, uint32_t* status,
+template <typename Buf, int NBITS>
+int dispatch_onesweep(adlhip_device* d, const Buf& src, const Buf& dst, const adlhip::PassTable* table, uint32_t* status,
                       uint32_t* tickets, size_t n, int start_bit)
 {
-    ADLHIP_DISPATCH_TILE(launch_onesweep, E, NBITS, d, src, dst, table, status, tickets, n, start_bit)
+    ADLHIP_DISPATCH_TILE(launch_onesweep, Buf, NBITS, d, src, dst, table, status, tickets, n, start_bit)
 }
 
-template <typename E>
-int onesweep_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, const std::vector<PassPlan>& plan)
+template <typename Buf>
+int onesweep_sort(adlhip_device* d, Buf data, Buf tmp, void* work, size_t n, const std::vector<PassPlan>& plan)
 {
+    typedef typename Buf::key_t key_t;
     const int P = (int)plan.size();
-    const uint32_t tile = current_tile(d, sizeof(E), n);
-    // offsets come from the worst-case layout the caller sized the buffer with
-    const OnesweepLayout L = onesweep_layout(d, n, max_passes_for(d, sizeof(E) == 4 ? 32 : 64), tile);
+    const uint32_t tile = buf_tile<Buf>(d, n);
+    const OnesweepLayout L = onesweep_layout(d, n, max_passes_for(d, Buf::kElemBytes == 4 ? 32 : 64), tile);
     char* wb = reinterpret_cast<char*>(work);
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(wb + L.off_ctrl);
     adlhip::PassTable* tables = reinterpret_cast<adlhip::PassTable*>(wb + L.off_tables);
@@ -428,15 +497,16 @@ int onesweep_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, const
     const uint32_t slice0 = per_wg * wgs_per_slice;
     const size_t hist_lds = (size_t)total_bins * 4;
     int rc = ADLHIP_FAILURE;
+    const key_t* hist_src = data.keys();
     auto run_hist = [&](auto kern) -> int {
         if (ensure_lds(kern, hist_lds)) return ADLHIP_FAILURE;
-        return launch(d, sizeof(E) == 4 ? "os_hist_u32" : "os_hist_e64", [&] {
-            hipLaunchKernelGGL(kern, dim3(wgs), dim3(adlhip::kHistNT), hist_lds, d->stream, data, part, (uint32_t)n, per_wg,
+        return launch(d, sizeof(key_t) == 4 ? "os_hist_u32" : "os_hist_e64", [&] {
+            hipLaunchKernelGGL(kern, dim3(wgs), dim3(adlhip::kHistNT), hist_lds, d->stream, hist_src, part, (uint32_t)n, per_wg,
                                slice0, desc, total_bins);
         });
     };
     switch (P) {   // pass count is a template parameter of the histogram kernel (descriptors stay in SGPRs)
-#define ADLHIP_HIST_CASE(N) case N: rc = run_hist(adlhip::onesweep_hist_kernel<E, N>); break;
+#define ADLHIP_HIST_CASE(N) case N: rc = run_hist(adlhip::onesweep_hist_kernel<key_t, N>); break;
         ADLHIP_HIST_CASE(1) ADLHIP_HIST_CASE(2) ADLHIP_HIST_CASE(3) ADLHIP_HIST_CASE(4) ADLHIP_HIST_CASE(5)
         ADLHIP_HIST_CASE(6) ADLHIP_HIST_CASE(7) ADLHIP_HIST_CASE(8) ADLHIP_HIST_CASE(9) ADLHIP_HIST_CASE(10)
         ADLHIP_HIST_CASE(11) ADLHIP_HIST_CASE(12) ADLHIP_HIST_CASE(13) ADLHIP_HIST_CASE(14) ADLHIP_HIST_CASE(15)
@@ -455,32 +525,32 @@ int onesweep_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, const
     });
     if (rc) return rc;
 
-    E* src = data;
-    E* dst = tmp;
+    Buf src = data;
+    Buf dst = tmp;
     for (int i = 0; i < P; ++i) {
         uint32_t* st = status + (size_t)i * rows * 256;
-        rc = (plan[i].nbits == 8) ? dispatch_onesweep<E, 8>(d, src, dst, tables + i, st, ctrl + i * 16, n, plan[i].start_bit)
-                                  : dispatch_onesweep<E, 4>(d, src, dst, tables + i, st, ctrl + i * 16, n, plan[i].start_bit);
+        rc = (plan[i].nbits == 8) ? dispatch_onesweep<Buf, 8>(d, src, dst, tables + i, st, ctrl + i * 16, n, plan[i].start_bit)
+                                  : dispatch_onesweep<Buf, 4>(d, src, dst, tables + i, st, ctrl + i * 16, n, plan[i].start_bit);
         if (rc) return rc;
         std::swap(src, dst);
     }
-    if (src != data) HIPCHK(hipMemcpyAsync(data, src, n * sizeof(E), hipMemcpyDeviceToDevice, d->stream));
+    if (!src.same(data)) return data.copy_from(src, n, d->stream);
     return ADLHIP_SUCCESS;
 }
 
-template <typename E>
-int three_kernel_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, const std::vector<PassPlan>& plan)
+template <typename Buf>
+int three_kernel_sort(adlhip_device* d, Buf data, Buf tmp, void* work, size_t n, const std::vector<PassPlan>& plan)
 {
-    E* src = data;
-    E* dst = tmp;
+    Buf src = data;
+    Buf dst = tmp;
     for (const PassPlan& p : plan) {
-        int rc = (p.nbits == 8) ? three_kernel_pass<E, 8>(d, src, dst, work, n, p.start_bit)
-                                : three_kernel_pass<E, 4>(d, src, dst, work, n, p.start_bit);
+        int rc = (p.nbits == 8) ? three_kernel_pass<Buf, 8>(d, src, dst, work, n, p.start_bit)
+                                : three_kernel_pass<Buf, 4>(d, src, dst, work, n, p.start_bit);
         if (rc) return rc;
         std::swap(src, dst);   // Pprims.cpp:397
     }
     // odd number of passes: result sits in the scratch buffer -> copy back (Pprims.cpp:400-403)
-    if (src != data) HIPCHK(hipMemcpyAsync(data, src, n * sizeof(E), hipMemcpyDeviceToDevice, d->stream));
+    if (!src.same(data)) return data.copy_from(src, n, d->stream);
     return ADLHIP_SUCCESS;
 }
 
@@ -514,9 +584,39 @@ int small_sort(adlhip_device* d, E* data, size_t n, const std::vector<PassPlan>&
 size_t sort_work_bytes(const adlhip_device* d, int elem_kind, size_t n)
 {
     const size_t a = work_bytes_three_kernel(d, n);
-    const size_t esz = elem_kind == ADLHIP_ELEM_U32 ? 4 : 8;
-    const size_t b = onesweep_layout(d, n, max_passes_for(d, esz == 4 ? 32 : 64), current_tile(d, esz, n)).total;   // as onesweep_sort<E>()
+    size_t b;
+    if (elem_kind == ADLHIP_ELEM_U32) b = onesweep_layout(d, n, max_passes_for(d, 32), buf_tile<AosBuf<uint32_t>>(d, n)).total;
+    else if (elem_kind == ADLHIP_ELEM_SOA32) b = onesweep_layout(d, n, max_passes_for(d, 64), buf_tile<SoaBuf>(d, n)).total;
+    else b = onesweep_layout(d, n, max_passes_for(d, 64), buf_tile<AosBuf<uint64_t>>(d, n)).total;   // as onesweep_sort<Buf>()
     return std::max(a, b);
+}
+
+// choose the path (shared by the AoS and SoA entry points)
+template <typename Buf>
+int run_sort(adlhip_device* d, Buf data, Buf tmp, void* work, size_t n, const std::vector<PassPlan>& plan)
+{
+    if (d->sort_algo < 0) {   // automatic choice by size (profiles/r1_ncurve.txt)
+        // the one-sweep path has more fixed cost (histogram, tables, status memset) and wins from ~96 MiB of data
+        if (n * Buf::kElemBytes < (size_t(96) << 20)) return three_kernel_sort<Buf>(d, data, tmp, work, n, plan);
+    }
+    // tile status words carry 30-bit counts: beyond 2^30 elements use the table-based pass
+    if (d->sort_algo == 1 || n >= (size_t(1) << 30)) return three_kernel_sort<Buf>(d, data, tmp, work, n, plan);
+    return onesweep_sort<Buf>(d, data, tmp, work, n, plan);
+}
+
+int check_sort_args(adlhip_device* d, int elem_kind, const void* a, const void* b, const void* work, size_t work_bytes,
+                    size_t n, int sort_bits, int max_bits)
+{
+    if (sort_bits < 4 || sort_bits > max_bits || (sort_bits & 3))   // Pprims.cpp:330
+        return fail("sort_bits must be a multiple of 4 in [4,%d], got %d", max_bits, sort_bits);
+    if (n > kMaxElems) return fail("n = %zu exceeds the supported maximum %zu", n, (size_t)kMaxElems);
+    if (n == 0) return ADLHIP_SUCCESS;
+    if (!a || !b || !work) return fail("null buffer passed to radix sort");
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15u)
+        return fail("sort buffers must be 16-byte aligned");
+    const size_t need = sort_work_bytes(d, elem_kind, n);
+    if (work_bytes < need) return fail("work buffer too small: %zu < %zu", work_bytes, need);
+    return ADLHIP_SUCCESS;
 }
 
 template <typename E>
@@ -524,24 +624,11 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
                int sort_bits, int max_bits)
 {
     if (bind(d)) return ADLHIP_FAILURE;
-    if (sort_bits < 4 || sort_bits > max_bits || (sort_bits & 3))   // Pprims.cpp:330
-        return fail("sort_bits must be a multiple of 4 in [4,%d], got %d", max_bits, sort_bits);
+    if (check_sort_args(d, elem_kind, data, tmp, work, work_bytes, n, sort_bits, max_bits)) return ADLHIP_FAILURE;
     if (n == 0) return ADLHIP_SUCCESS;
-    if (n > kMaxElems) return fail("n = %zu exceeds the supported maximum %zu", n, (size_t)kMaxElems);
-    if (!data || !tmp || !work) return fail("null buffer passed to radix sort");
-    if ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(tmp)) & 15u)
-        return fail("sort buffers must be 16-byte aligned");
-    const size_t need = sort_work_bytes(d, elem_kind, n);
-    if (work_bytes < need) return fail("work buffer too small: %zu < %zu", work_bytes, need);
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
-    if (d->sort_algo < 0) {   // automatic choice by size (profiles/r1_ncurve.txt)
-        if (n <= kSmallMax) return small_sort<E>(d, data, n, plan);   // one workgroup, one launch
-        // the one-sweep path has more fixed cost (histogram, tables, status memset) and wins from ~96 MiB of data
-        if (n * sizeof(E) < (size_t(96) << 20)) return three_kernel_sort<E>(d, data, tmp, work, n, plan);
-    }
-    // tile status words carry 30-bit counts: beyond 2^30 elements use the table-based pass
-    if (d->sort_algo == 1 || n >= (size_t(1) << 30)) return three_kernel_sort<E>(d, data, tmp, work, n, plan);
-    return onesweep_sort<E>(d, data, tmp, work, n, plan);
+    if (d->sort_algo < 0 && n <= kSmallMax) return small_sort<E>(d, data, n, plan);   // one workgroup, one launch
+    return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, n, plan);
 }
 
 }  // namespace
@@ -787,8 +874,8 @@ int adlhip_unmap(adlhip_device* d, void* dptr, void* hptr, size_t bytes)
 int adlhip_radix_sort_scratch_bytes(adlhip_device* d, int elem_kind, size_t n, size_t* tmp_bytes, size_t* work_bytes)
 {
     if (!d) return fail("null device handle");
-    if (elem_kind < ADLHIP_ELEM_U32 || elem_kind > ADLHIP_ELEM_U64) return fail("bad element kind %d", elem_kind);
-    const size_t esz = elem_kind == ADLHIP_ELEM_U32 ? 4 : 8;
+    if (elem_kind < ADLHIP_ELEM_U32 || elem_kind > ADLHIP_ELEM_SOA32) return fail("bad element kind %d", elem_kind);
+    const size_t esz = (elem_kind == ADLHIP_ELEM_U32 || elem_kind == ADLHIP_ELEM_SOA32) ? 4 : 8;   // SoA: per array
     if (tmp_bytes) *tmp_bytes = align_up(n * esz, 256);
     if (work_bytes) *work_bytes = sort_work_bytes(d, elem_kind, n);
     return ADLHIP_SUCCESS;
@@ -807,6 +894,19 @@ int adlhip_radix_sort_kv32(adlhip_device* d, void* pairs, void* tmp, void* work,
 int adlhip_radix_sort_u64(adlhip_device* d, uint64_t* keys, uint64_t* tmp, void* work, size_t work_bytes, size_t n, int sort_bits)
 {
     return sort_entry<uint64_t>(d, ADLHIP_ELEM_U64, keys, tmp, work, work_bytes, n, sort_bits, 64);
+}
+
+int adlhip_radix_sort_soa32(adlhip_device* d, uint32_t* keys, uint32_t* vals, uint32_t* tmp_keys, uint32_t* tmp_vals,
+                            void* work, size_t work_bytes, size_t n, int sort_bits)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (check_sort_args(d, ADLHIP_ELEM_SOA32, keys, tmp_keys, work, work_bytes, n, sort_bits, 32)) return ADLHIP_FAILURE;
+    if (n == 0) return ADLHIP_SUCCESS;
+    if (!vals || !tmp_vals) return fail("null value buffer passed to radix sort");
+    if ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(tmp_vals)) & 15u)
+        return fail("sort buffers must be 16-byte aligned");
+    const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
+    return run_sort<SoaBuf>(d, SoaBuf{keys, vals}, SoaBuf{tmp_keys, tmp_vals}, work, n, plan);
 }
 
 // ---- scan ---------------------------------------------------------------------------------------
@@ -891,7 +991,7 @@ int adlhip_partition_msb_u32(adlhip_device* d, const uint32_t* in, uint32_t* out
     if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) return fail("buffers must be 16-byte aligned");
     // one three-kernel pass on the top byte (the top `lg` bits decide the bucket; ordering by the
     // whole top byte refines buckets without mixing them), then fold the 256 digit totals into buckets
-    int rc = three_kernel_pass<uint32_t, 8>(d, in, out, work, n, 24);
+    int rc = three_kernel_pass<AosBuf<uint32_t>, 8>(d, AosBuf<uint32_t>{const_cast<uint32_t*>(in)}, AosBuf<uint32_t>{out}, work, n, 24);
     if (rc) return rc;
     uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + table_bytes(d, n, kMinTile));
     return launch(d, "fold_buckets", [&] {
@@ -1034,6 +1134,26 @@ int adlhip_debug_set_stamp_buffer(adlhip_device* d, void* dptr)
     return ADLHIP_SUCCESS;
 }
 #endif
+
+int adlhip_profile_write_csv(adlhip_device* d, const char* path)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!path) return fail("null path");
+    if (fold_profile(d)) return ADLHIP_FAILURE;
+    FILE* probe = fopen(path, "r");
+    const bool fresh = probe == nullptr;
+    if (probe) fclose(probe);
+    FILE* f = fopen(path, "a");
+    if (!f) return fail("cannot open %s for appending", path);
+    if (fresh) fprintf(f, "\"kernel\",\"launches\",\"total_ms\",\"avg_ms\"\n");
+    for (const std::string& nm : d->prof_order) {
+        const ProfEntry& e = d->prof[nm];
+        fprintf(f, "\"%s\",%llu,%.6f,%.6f\n", nm.c_str(), (unsigned long long)e.launches, e.total_ms,
+                e.launches ? e.total_ms / (double)e.launches : 0.0);
+    }
+    fclose(f);
+    return ADLHIP_SUCCESS;
+}
 
 // ---- probes ---------------------------------------------------------------------------------------
 

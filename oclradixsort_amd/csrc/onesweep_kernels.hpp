@@ -40,12 +40,7 @@
 #ifndef ADLHIP_WRITE_UNROLL
 #define ADLHIP_WRITE_UNROLL 4
 #endif
-#ifndef ADLHIP_NT_STORES
-#define ADLHIP_NT_STORES 0
-#endif
-#ifndef ADLHIP_NT_LOADS
-#define ADLHIP_NT_LOADS 0
-#endif
+
 
 namespace adlhip {
 
@@ -319,12 +314,12 @@ __device__ __forceinline__ u32x4 lookback_exclusive4(__amdgpu_buffer_rsrc_t rsrc
 //   wave 0 then: look-back over its chain, publish inclusive prefix, global offsets    | barrier C
 //   write-out: consecutive lanes store consecutive elements of a digit's run.
 // ------------------------------------------------------------------------------------------
-template <typename E, int NBITS, int NT, int K, int RANK>
-__global__ __launch_bounds__(NT) void onesweep_chain_kernel(const E* __restrict__ src, E* __restrict__ dst,
-                                                            const PassTable* __restrict__ table, uint32_t* status,
+template <typename IO, int NBITS, int NT, int K, int RANK>
+__global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTable* __restrict__ table, uint32_t* status,
                                                             uint32_t status_bytes, uint32_t* tickets, uint32_t* fault,
                                                             uint32_t n, int start_bit)
 {
+    typedef typename IO::elem_t E;
     using C = TileCfg<E, NBITS, NT, K>;
     constexpr int BINS = C::BINS;
     constexpr int NW = C::NW;
@@ -376,20 +371,14 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(const E* __restrict_
     const uint32_t wbase = (uint32_t)(w * 64 * K + lane);
     E e[K];
     {
-        const E* p = src + (size_t)elem0 + wbase;
+        const typename IO::Cursor p = io.cursor((size_t)elem0 + wbase);
         if (valid == (uint32_t)C::TILE) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-#if ADLHIP_NT_LOADS
-                e[j] = __builtin_nontemporal_load(&p[j * 64]);
-#else
-                e[j] = p[j * 64];
-#endif
-            }
+            for (int j = 0; j < K; ++j) e[j] = p.at(j * 64);
         } else {
             const int rem = (int)valid - (int)wbase;   // element j of this lane's column exists iff j*64 < rem
 #pragma unroll
-            for (int j = 0; j < K; ++j) e[j] = (j * 64 < rem) ? p[j * 64] : ~E(0);
+            for (int j = 0; j < K; ++j) e[j] = (j * 64 < rem) ? p.at(j * 64) : ~E(0);
         }
     }
 
@@ -485,13 +474,7 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(const E* __restrict_
             const E v = s_elems[tid + i * NT];
             const uint32_t d = digit_of<NBITS>(v, start_bit);
             const uint32_t g = s_goff[d] + (uint32_t)(tid + i * NT);
-            if (g < n) {   // always true for a sound offset (guards a faulted look-back)
-#if ADLHIP_NT_STORES
-                __builtin_nontemporal_store(v, &dst[(size_t)g]);
-#else
-                dst[(size_t)g] = v;
-#endif
-            }
+            if (g < n) io.store((size_t)g, v);   // always true for a sound offset (guards a faulted look-back)
         }
     }
     ADLHIP_STAMP(tile, 10);

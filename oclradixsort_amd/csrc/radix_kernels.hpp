@@ -143,6 +143,44 @@ struct TileCfg {
     static constexpr size_t LDS_BYTES = OFF_MISC + 64;
 };
 
+// Where a tile's elements come from and go to.
+//   AosIO<E>: one array of E (u32 keys, u64 keys, or 8-byte {key, value} pairs).
+//   SoaIO   : separate u32 key and u32 value arrays -- the layout of the reference's never-launched
+//             SortAndScatterKernel(gSrc, gSrcVal, ...) (RadixSortKeyValueKernels.cl:354-509).
+//             A pair travels through registers and LDS as one u64 {key low, value high}, so the tile body
+//             is the one the AoS pairs use; only the global loads/stores differ.
+template <typename E>
+struct AosIO {
+    typedef E elem_t;
+    const E* src;
+    E* dst;
+    // cursor = one 64-bit pointer per tile; elements are then read at constant offsets from it
+    struct Cursor {
+        const E* p;
+        __device__ __forceinline__ E at(int off) const { return p[off]; }
+    };
+    __device__ __forceinline__ Cursor cursor(size_t base) const { return Cursor{src + base}; }
+    __device__ __forceinline__ void store(size_t i, E v) const { dst[i] = v; }
+};
+struct SoaIO {
+    typedef uint64_t elem_t;
+    const uint32_t* ksrc;
+    const uint32_t* vsrc;
+    uint32_t* kdst;
+    uint32_t* vdst;
+    struct Cursor {
+        const uint32_t* k;
+        const uint32_t* v;
+        __device__ __forceinline__ uint64_t at(int off) const { return (uint64_t)k[off] | ((uint64_t)v[off] << 32); }
+    };
+    __device__ __forceinline__ Cursor cursor(size_t base) const { return Cursor{ksrc + base, vsrc + base}; }
+    __device__ __forceinline__ void store(size_t i, uint64_t v) const
+    {
+        kdst[i] = (uint32_t)v;
+        vdst[i] = (uint32_t)(v >> 32);
+    }
+};
+
 // Stable rank of each of a lane's K elements among the wave's elements with the same digit, in
 // (item, lane) order; my_wcnt[digit] ends up holding the wave's count per digit (it must be zero on
 // entry).  RANK == 1: one returning DS atomic per element -- on gfx950 a returning DS atomic issued
@@ -207,11 +245,11 @@ __device__ __forceinline__ void rank_in_wave(const E (&e)[K], uint32_t (&rnk)[K]
 // `valid` < TILE only for the globally last tile; the missing slots are padded with all-ones keys,
 // which rank after every real element (max digit, highest indices, stable) and are never stored
 // -- the reference's key-value kernel pads the same way (RadixSortKeyValueKernels.cl:554-563).
-template <typename E, int NBITS, int NT, int K, int RANK, typename BinOffsetFn>
-__device__ __forceinline__ void sort_scatter_tile(const E* __restrict__ src, E* __restrict__ dst,
-                                                  uint32_t tile_base, uint32_t valid, uint32_t n_total,
+template <typename IO, int NBITS, int NT, int K, int RANK, typename BinOffsetFn>
+__device__ __forceinline__ void sort_scatter_tile(const IO& io, uint32_t tile_base, uint32_t valid, uint32_t n_total,
                                                   int start_bit, unsigned char* smem, BinOffsetFn&& bin_offset)
 {
+    typedef typename IO::elem_t E;
     using C = TileCfg<E, NBITS, NT, K>;
     constexpr int BINS = C::BINS;
     constexpr int NW = C::NW;
@@ -238,14 +276,14 @@ __device__ __forceinline__ void sort_scatter_tile(const E* __restrict__ src, E* 
     E e[K];
     {
         const uint32_t wbase = (uint32_t)(w * 64 * K + lane);
-        const E* p = src + (size_t)tile_base + wbase;
+        const typename IO::Cursor p = io.cursor((size_t)tile_base + wbase);
         if (valid == (uint32_t)C::TILE) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) e[j] = p[j * 64];
+            for (int j = 0; j < K; ++j) e[j] = p.at(j * 64);
         } else {
             const int rem = (int)valid - (int)wbase;   // element j of this lane's column exists iff j*64 < rem
 #pragma unroll
-            for (int j = 0; j < K; ++j) e[j] = (j * 64 < rem) ? p[j * 64] : ~E(0);
+            for (int j = 0; j < K; ++j) e[j] = (j * 64 < rem) ? p.at(j * 64) : ~E(0);
         }
     }
 
@@ -330,7 +368,7 @@ __device__ __forceinline__ void sort_scatter_tile(const E* __restrict__ src, E* 
             const E v = s_elems[tid + i * NT];
             const uint32_t d = digit_of<NBITS>(v, start_bit);
             const uint32_t g = s_goff[d] + (uint32_t)(tid + i * NT);
-            if (g < n_total) dst[(size_t)g] = v;   // always true for a sound offset
+            if (g < n_total) io.store((size_t)g, v);   // always true for a sound offset
         }
     }
     ADLHIP_STAMP(stamp_tile, 9);
@@ -446,13 +484,13 @@ __global__ __launch_bounds__(NT) void radix_scan_table_kernel(uint32_t* __restri
 
 // Stable local sort + scatter of the workgroup's run of tiles, carrying per-digit offsets from tile
 // to tile (RadixSort32Kernels.cl:493-631 behaviour).
-template <typename E, int NBITS, int NT, int K, int RANK>
-__global__ __launch_bounds__(NT) void radix_scatter_kernel(const E* __restrict__ src, E* __restrict__ dst,
-                                                           const uint32_t* __restrict__ table,
+template <typename IO, int NBITS, int NT, int K, int RANK>
+__global__ __launch_bounds__(NT) void radix_scatter_kernel(IO io, const uint32_t* __restrict__ table,
                                                            const uint32_t* __restrict__ totals, uint32_t n,
                                                            int n_wgs, int start_bit, uint32_t tiles_per_wg,
                                                            uint32_t num_tiles)
 {
+    typedef typename IO::elem_t E;
     using C = TileCfg<E, NBITS, NT, K>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + C::OFF_WSUM);
@@ -470,7 +508,7 @@ __global__ __launch_bounds__(NT) void radix_scatter_kernel(const E* __restrict__
         const uint32_t tile_base = t * (uint32_t)C::TILE;
         const uint32_t left = n - tile_base;
         const uint32_t valid = left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE;
-        sort_scatter_tile<E, NBITS, NT, K, RANK>(src, dst, tile_base, valid, n, start_bit, smem,
+        sort_scatter_tile<IO, NBITS, NT, K, RANK>(io, tile_base, valid, n, start_bit, smem,
                                            [&](int /*b*/, uint32_t cnt) {
                                                const uint32_t g = carry;
                                                carry += cnt;

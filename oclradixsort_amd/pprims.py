@@ -22,6 +22,7 @@ from .adl import Buffer
 ELEM_U32 = 0
 ELEM_KV32 = 1
 ELEM_U64 = 2
+ELEM_SOA32 = 3
 
 
 class Pprims:
@@ -84,6 +85,24 @@ class Pprims:
             self._sort(device, ELEM_KV32, lib.adlhip_radix_sort_kv32, inout, n, sortBits)
         else:
             raise AdlHipError("radixSort: unsupported element type %s" % inout.dtype)
+
+    def radixSortSoA(self, device, keys, values, n, sortBits=32):
+        """Key-value sort on separate u32 key and u32 value buffers (structure of arrays): ascending
+        by key, stable, values follow their keys.  Same contract as radixSort on {key, value} pairs."""
+        assert keys.dtype == np.uint32 and values.dtype == np.uint32
+        if device is None:
+            raise AdlHipError("radixSortSoA needs a device")
+        n = int(n)
+        lib = _lib.load()
+        tb = ctypes.c_size_t()
+        wb = ctypes.c_size_t()
+        check(lib.adlhip_radix_sort_scratch_bytes(device._h, ELEM_SOA32, n, ctypes.byref(tb), ctypes.byref(wb)),
+              "adlhip_radix_sort_scratch_bytes")
+        self._scratch(device, 2 * tb.value, wb.value)          # tmp keys + tmp values, back to back
+        tmp_k = self.m_tmp.ptr()
+        tmp_v = ctypes.c_void_p(self.m_tmp.m_ptr + tb.value) if self.m_tmp.m_ptr else None
+        check(lib.adlhip_radix_sort_soa32(device._h, keys.ptr(), values.ptr(), tmp_k, tmp_v, self.m_work.ptr(),
+                                          self.m_work.getSize(), n, int(sortBits)), "radixSortSoA")
 
     def radixSort64(self, device, inout, n, sortBits=64):
         assert inout.dtype == np.uint64

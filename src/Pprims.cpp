@@ -102,6 +102,24 @@ void Pprims::radixSort(const adl::Device* device, const adl::Buffer<u64>& inout,
     ADLASSERT(rc == ADLHIP_SUCCESS);
 }
 
+void Pprims::radixSort(const adl::Device* device, const adl::Buffer<u32>& keys, const adl::Buffer<u32>& values, int n,
+                       int sortBits)
+{
+    ADLASSERT(n >= 0);
+    if (n <= 0) return;
+    ADLASSERT(enableSortOnDevice(device));   // the structure-of-arrays variant exists on the device path only
+    if (!enableSortOnDevice(device)) return;
+    ADLASSERT((sortBits & 0x3) == 0);
+    size_t tb = 0, wb = 0;
+    ADLASSERT(adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_SOA32, (size_t)n, &tb, &wb) == ADLHIP_SUCCESS);
+    reserve(device, 2 * tb, wb);   // scratch keys + scratch values, back to back
+    const int rc = adlhip_radix_sort_soa32(device->hip(), keys.m_ptr, values.m_ptr, (u32*)m_tmp->m_ptr,
+                                           (u32*)(m_tmp->m_ptr + tb), m_work->m_ptr, (size_t)m_work->getSize(), (size_t)n,
+                                           sortBits);
+    if (rc != ADLHIP_SUCCESS) TH_LOG_ERROR("Pprims::radixSort: %s\n", adlhip_last_error());
+    ADLASSERT(rc == ADLHIP_SUCCESS);
+}
+
 void Pprims::scan(const adl::Device* device, adl::Buffer<int>& dst, const adl::Buffer<int>& src, int n, u32* sumOut)
 {
     if (device == 0 || device->hip() == 0) {   // Pprims.cpp:124-127: no host fallback for scan

@@ -378,8 +378,14 @@ def test_stopwatch_and_profiling(dev, pp):
     pp.radixSort(dev, b, n)
     sw.stop()
     ms = sw.getMs()
+    csv_path = "/tmp/adlhip_profile_test.csv"
+    if os.path.exists(csv_path):
+        os.remove(csv_path)
+    dev.writeProfileCsv(csv_path)
     prof = dev.profile(reset=True)
     dev.toggleProfiling(False)
+    rows = open(csv_path).read().splitlines()
+    assert rows[0] == '"kernel","launches","total_ms","avg_ms"' and len(rows) >= 3
     assert ms > 0
     assert any(k.startswith(("onesweep_u32", "scatter_u32")) for k in prof), prof
     assert sum(v[1] for v in prof.values()) > 0
@@ -491,3 +497,26 @@ def test_two_pprims_and_two_devices_do_not_interfere(dev):
     finally:
         p1.close(); p2.close()
         DeviceUtils.deallocate(d2)
+
+
+# ---------------------------------------------------------------------------------------------
+# structure-of-arrays key-value sort
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("algo", [(-1, 8, -1, 1), (0, 8, -1, 1), (1, 8, -1, 1), (0, 4, -1, 0), (1, 4, 0, 1)],
+                         ids=["auto8", "onesweep8", "threekernel8", "onesweep4-ballot", "threekernel4-256x16"])
+def test_soa_key_value_sort(dev, pp, algo):
+    set_algo(dev, algo)
+    rng = np.random.RandomState(17)
+    for n in (1, 255, 4097, 70001, 1 << 20, (1 << 24) + 3):
+        for keys in (oracle.keys_u32(n, seed=n), (rng.randint(0, 37, n)).astype(np.uint32)):     # random, and many duplicates
+            vals = np.arange(n, dtype=np.uint32) * np.uint32(2654435761)
+            kb, vb = Buffer(dev, n, np.uint32), Buffer(dev, n, np.uint32)
+            kb.write(keys); vb.write(vals)
+            bits = 32 if n != 70001 else 20
+            pp.radixSortSoA(dev, kb, vb, n, bits)
+            gk, gv = kb.toHost(), vb.toHost()
+            pairs = keys.astype(np.uint64) | (vals.astype(np.uint64) << np.uint64(32))
+            want = oracle.sort_kv32(pairs) if bits == 32 else oracle.sort_e64_bits(pairs, bits)
+            assert np.array_equal(gk, (want & np.uint64(0xffffffff)).astype(np.uint32)), (n, bits)
+            assert np.array_equal(gv, (want >> np.uint64(32)).astype(np.uint32)), (n, bits)
+            kb.release(); vb.release()

@@ -19,9 +19,10 @@ d = DeviceUtils.allocate()
 for kv in args.param:
     k, v = kv.split('='); d.setParam(k, int(v))
 p = Pprims()
-dtype = np.uint32 if args.kind == "u32" else np.uint64
-gen_kind = {"u32": 0, "kv": 1, "u64": 2}[args.kind]
+dtype = np.uint32 if args.kind in ("u32", "soa") else np.uint64
+gen_kind = {"u32": 0, "kv": 1, "u64": 2, "soa": 0}[args.kind]
 bufs = [Buffer(d, n, dtype) for _ in range(K)]
+vbufs = [Buffer(d, n, np.uint32) for _ in range(K)] if args.kind == "soa" else []
 if args.configs:
     configs = [tuple(int(x) for x in c.split(":")) for c in args.configs.split(",")]
 else:
@@ -31,6 +32,9 @@ if args.verify:
     import oracle
     if args.kind == "u32": want = oracle.sort_u32(oracle.keys_u32(n, 1000))
     elif args.kind == "kv": want = oracle.sort_kv32(oracle.pairs_kv32(n, 1000))
+    elif args.kind == "soa":
+        pr = oracle.keys_u32(n, 1000).astype(np.uint64) | (oracle.keys_u32(n, 5000).astype(np.uint64) << np.uint64(32))
+        want = (oracle.sort_kv32(pr) & np.uint64(0xffffffff)).astype(np.uint32)
     else: want = oracle.sort_u64(oracle.keys_u64(n, 1000))
 print("%-28s %9s %9s  %s" % ("algo:bits:tile:rank", "ms/sort", "G/s", "per-kernel avg ms"))
 for (algo, bits, tile, rank) in configs:
@@ -42,13 +46,16 @@ for (algo, bits, tile, rank) in configs:
     def run(profile):
         for i, b in enumerate(bufs):
             b.generate(n, seed=1000 + i, kind=gen_kind)
+        for i, b in enumerate(vbufs):
+            b.generate(n, seed=5000 + i, kind=0)
         DeviceUtils.waitForCompletion(d)
         sw = Stopwatch(d)
         if profile:
             d.toggleProfiling(True); d.profile(reset=True)
         sw.start()
-        for b in bufs:
+        for i, b in enumerate(bufs):
             if args.kind == "u64": p.radixSort64(d, b, n)
+            elif args.kind == "soa": p.radixSortSoA(d, b, vbufs[i], n)
             else: p.radixSort(d, b, n)
         sw.stop()
         ms = sw.getMs() / K
@@ -67,5 +74,5 @@ for (algo, bits, tile, rank) in configs:
         print("%-28s %9.3f %9.2f  %s%s" % ("%d:%d:%d:%d" % (algo, bits, tile, rank), ms, n / ms / 1e6, ks, ok), flush=True)
     except Exception as e:
         print("%-28s FAILED %s" % ("%d:%d:%d:%d" % (algo, bits, tile, rank), e), flush=True)
-for b in bufs: b.release()
+for b in bufs + vbufs: b.release()
 p.close(); DeviceUtils.deallocate(d)
