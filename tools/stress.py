@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Soak test of the inter-workgroup look-back protocol: many back-to-back one-sweep sorts of random sizes,
+element kinds and key distributions, every result checked (sortedness + multiset checksum on the device
+result copied back, full oracle comparison for the smaller ones), fault word checked at every sync.
+   python tools/stress.py [--seconds 60]"""
+import argparse, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle
+from oclradixsort_amd import Buffer, DeviceUtils, Pprims
+ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=60.0); args = ap.parse_args()
+d = DeviceUtils.allocate(); p = Pprims()
+rng = np.random.RandomState(2026)
+t_end = time.time() + args.seconds
+it = 0; elems = 0
+def checks(a):
+    a64 = a.astype(np.uint64)
+    return int(a64.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(a64)) if a.size else 0
+while time.time() < t_end:
+    it += 1
+    kind = rng.choice(["u32", "kv", "u64", "soa"])
+    n = int(2 ** rng.uniform(10, 25.5)) + int(rng.randint(0, 1000))
+    algo = int(rng.choice([0, 0, 0, 1, -1])); bits = int(rng.choice([8, 8, 8, 4])); tile = int(rng.choice([-1, -1, 0, 1, 2, 5]))
+    d.setParam("sort.algo", algo); d.setParam("sort.digit_bits", bits); d.setParam("sort.tile", tile)
+    dist = rng.choice(["uniform", "lowbits", "fewvals", "sortedish"])
+    if kind in ("u32", "soa", "kv"):
+        k = oracle.keys_u32(n, seed=it)
+        if dist == "lowbits": k &= np.uint32(0xffff)
+        elif dist == "fewvals": k = (k % np.uint32(5)) * np.uint32(0x01010101)
+        elif dist == "sortedish": k = np.sort(k)
+    if kind == "u32":
+        b = Buffer(d, n, np.uint32); b.write(k)
+        reps = int(rng.randint(1, 4))
+        for _ in range(reps): p.radixSort(d, b, n)          # re-sorting sorted data stresses the low-entropy paths
+        out = b.toHost(); b.release()
+        assert np.all(out[1:] >= out[:-1]) and checks(out) == checks(k), (it, kind, n, algo, bits, tile, dist)
+        if n < (1 << 22): assert np.array_equal(out, oracle.sort_u32(k)), (it, kind, n)
+    elif kind == "kv":
+        pr = k.astype(np.uint64) | (np.arange(n, dtype=np.uint64) << np.uint64(32))
+        b = Buffer(d, n, np.uint64); b.write(pr); p.radixSort(d, b, n); out = b.toHost(); b.release()
+        kk = out & np.uint64(0xffffffff); vv = out >> np.uint64(32)
+        assert np.all(kk[1:] >= kk[:-1]); same = kk[1:] == kk[:-1]
+        assert np.all(vv[1:][same] > vv[:-1][same]) and checks(out) == checks(pr), (it, kind, n, algo, bits, tile, dist)
+    elif kind == "soa":
+        v = np.arange(n, dtype=np.uint32)
+        kb = Buffer(d, n, np.uint32); vb = Buffer(d, n, np.uint32); kb.write(k); vb.write(v)
+        p.radixSortSoA(d, kb, vb, n); ok, ov = kb.toHost(), vb.toHost(); kb.release(); vb.release()
+        assert np.all(ok[1:] >= ok[:-1]); same = ok[1:] == ok[:-1]
+        assert np.all(ov[1:][same] > ov[:-1][same]) and np.array_equal(k[ov], ok), (it, kind, n, algo, bits, tile, dist)
+    else:
+        k64 = oracle.keys_u64(n, seed=it)
+        if dist == "lowbits": k64 &= np.uint64(0xffffff)
+        b = Buffer(d, n, np.uint64); b.write(k64); p.radixSort64(d, b, n); out = b.toHost(); b.release()
+        assert np.all(out[1:] >= out[:-1]) and checks(out) == checks(k64), (it, kind, n, algo, bits, tile, dist)
+    elems += n
+print("stress ok: %d sorts, %.1f M elements, %.0f s, no mismatch, no look-back fault" % (it, elems / 1e6, args.seconds))
+p.close(); DeviceUtils.deallocate(d)
