@@ -79,7 +79,7 @@ __host__ __device__ inline uint32_t joint_bins(int nbits) { return (uint32_t)kCh
 // Up-front histograms: for every pass p the joint histogram of (chain, digit):
 //   p >= 1: chain = top nibble of pass p-1's digit (bits [start_p - 4, start_p)), digit = pass p's;
 //   p == 0: chain = which sixteenth ("slice") of the input the element lies in (workgroup-uniform).
-// partial[wg * total_bins + bin_off[p] + chain * (1 << nbits[p]) + digit]
+// partial[wg * total_bins + bin_off[p] + (p == 0 ? chain * (1 << nbits[0]) + digit : digit * 16 + chain)]
 // ------------------------------------------------------------------------------------------
 // P (number of passes) is a template parameter so that the loop over passes unrolls with constant
 // indices: the pass descriptors then sit in SGPRs (indexed dynamically they were re-loaded from the
@@ -105,13 +105,14 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
         auto bin_of = [&](E x, int p) -> uint32_t {
             const int sb = desc.start_bit[p];
             const int nb = desc.nbits[p];
-            if (p == 0) return (chain0 << nb) | ((uint32_t)x & ((1u << nb) - 1u));   // pass 0 starts at bit 0
-            // nb + 4 contiguous bits starting at sb - 4: v = digit << 4 | nibble  ->  bin = nibble << nb | digit
+            // pass 0 (starts at bit 0; the chain is workgroup-uniform): bin = chain * 2^nb + digit.  With the
+            // uniform chain in the LOW bits every lane would hit one of 4 LDS banks.
+            if (p == 0) return (chain0 << nb) | ((uint32_t)x & ((1u << nb) - 1u));
+            // p >= 1: bin = digit * 16 + chain = the nb + 4 contiguous key bits from sb - 4 (one v_bfe_u32)
             uint32_t v;
             if constexpr (sizeof(E) == 8) v = (uint32_t)((uint64_t)x >> (sb - 4));
             else v = (uint32_t)x >> (sb - 4);
-            v &= (1u << (nb + 4)) - 1u;
-            return ((v & 15u) << nb) | (v >> 4);
+            return v & ((1u << (nb + 4)) - 1u);
         };
         auto bump = [&](E x) {
             uint32_t off = 0u;
@@ -156,8 +157,15 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
         const uint32_t nvec = (end - begin) / VEC;
         const Vec* vsrc = reinterpret_cast<const Vec*>(src + begin);
         uint32_t i = (uint32_t)tid;
-        for (; i + 3u * kHistNT < nvec; i += 4u * kHistNT) {
+        // software-pipelined: the next four vectors are in flight while the current four are histogrammed
+        if (i + 3u * kHistNT < nvec) {
             Vec a = vsrc[i], b = vsrc[i + kHistNT], c = vsrc[i + 2 * kHistNT], d4 = vsrc[i + 3 * kHistNT];
+            i += 4u * kHistNT;
+            for (; i + 3u * kHistNT < nvec; i += 4u * kHistNT) {
+                const Vec na = vsrc[i], nb = vsrc[i + kHistNT], nc = vsrc[i + 2 * kHistNT], nd = vsrc[i + 3 * kHistNT];
+                bump4(a, b, c, d4);
+                a = na; b = nb; c = nc; d4 = nd;
+            }
             bump4(a, b, c, d4);
         }
         for (; i < nvec; i += kHistNT) {
@@ -210,14 +218,14 @@ __global__ __launch_bounds__(256) void onesweep_tables_kernel(const uint32_t* __
     const uint32_t bins = 1u << nb;
     uint32_t off = 0u;
     for (int q = 0; q < p; ++q) off += joint_bins(desc.nbits[q]);
-    const uint32_t* J = joint + off;   // [kChains][bins]
+    const uint32_t* J = joint + off;   // pass 0: [kChains][bins]; later passes: [bins][kChains]
     PassTable* T = tables + p;
 
     uint32_t col[kChains];
     uint32_t tot = 0u;
 #pragma unroll
     for (int c = 0; c < kChains; ++c) {
-        col[c] = ((uint32_t)tid < bins) ? J[(uint32_t)c * bins + (uint32_t)tid] : 0u;
+        col[c] = ((uint32_t)tid < bins) ? J[p == 0 ? (uint32_t)c * bins + (uint32_t)tid : (uint32_t)tid * (uint32_t)kChains + (uint32_t)c] : 0u;
         tot += col[c];
     }
     const uint32_t gb = block_excl_scan_u32<256>(tot, wsum, nullptr);

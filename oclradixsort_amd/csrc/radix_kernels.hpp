@@ -436,8 +436,14 @@ __global__ __launch_bounds__(NT) void radix_count_kernel(const E* __restrict__ s
         const Vec* vsrc = reinterpret_cast<const Vec*>(src + begin);
         uint32_t i = (uint32_t)tid;
         // 4 independent 16-byte loads in flight per lane
-        for (; i + 3u * NT < nvec; i += 4u * NT) {
+        if (i + 3u * NT < nvec) {   // software-pipelined: next loads in flight while the current vectors are counted
             Vec a = vsrc[i], b = vsrc[i + NT], c = vsrc[i + 2 * NT], d4 = vsrc[i + 3 * NT];
+            i += 4u * NT;
+            for (; i + 3u * NT < nvec; i += 4u * NT) {
+                const Vec na = vsrc[i], nb = vsrc[i + NT], nc = vsrc[i + 2 * NT], nd = vsrc[i + 3 * NT];
+                bump4(a, b, c, d4);
+                a = na; b = nb; c = nc; d4 = nd;
+            }
             bump4(a, b, c, d4);
         }
         for (; i < nvec; i += NT) {
