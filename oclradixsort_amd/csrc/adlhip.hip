@@ -477,9 +477,8 @@ int onesweep_sort(adlhip_device* d, Buf data, Buf tmp, void* work, size_t n, con
     uint32_t* status = reinterpret_cast<uint32_t*>(wb + L.off_status);
     const size_t rows = status_rows(n, tile);
 
-    // zero the tickets and every status word of the passes we run (status is contiguous)
-    HIPCHK(hipMemsetAsync(ctrl, 0, 1024, d->stream));
-    HIPCHK(hipMemsetAsync(status, 0, (size_t)P * rows * 256 * 4, d->stream));
+    // the tickets and every status word of the passes we run (status is contiguous) are zeroed by the histogram kernel
+    const size_t status_vecs = (size_t)P * rows * 256 * 4 / 16;
 
     adlhip::PassDesc desc;
     desc.num_passes = P;
@@ -502,7 +501,8 @@ int onesweep_sort(adlhip_device* d, Buf data, Buf tmp, void* work, size_t n, con
         if (ensure_lds(kern, hist_lds)) return ADLHIP_FAILURE;
         return launch(d, sizeof(key_t) == 4 ? "os_hist_u32" : "os_hist_e64", [&] {
             hipLaunchKernelGGL(kern, dim3(wgs), dim3(adlhip::kHistNT), hist_lds, d->stream, hist_src, part, (uint32_t)n, per_wg,
-                               slice0, desc, total_bins);
+                               slice0, desc, total_bins, reinterpret_cast<adlhip::u32x4*>(ctrl),
+                               reinterpret_cast<adlhip::u32x4*>(status), status_vecs);
         });
     };
     switch (P) {   // pass count is a template parameter of the histogram kernel (descriptors stay in SGPRs)

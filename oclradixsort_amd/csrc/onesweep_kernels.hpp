@@ -32,6 +32,7 @@
 //     Every spin is bounded; a wait that exceeds its bound raises the device fault word, which
 //     adlhip_sync() reports.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -88,11 +89,20 @@ template <typename E, int P>
 __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restrict__ src,
                                                                 uint32_t* __restrict__ partial, uint32_t n,
                                                                 uint32_t chunk, uint32_t slice0, PassDesc desc,
-                                                                uint32_t total_bins)
+                                                                uint32_t total_bins, u32x4* __restrict__ tickets,
+                                                                u32x4* __restrict__ status, size_t status_vecs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
     const int tid = (int)threadIdx.x;
+    // Zero the chain tickets (1 KiB) and the status rows of all passes on the way: fire-and-forget stores that
+    // drain under the key stream, instead of two memset launches in front of every sort.
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        if (blockIdx.x == 0 && tid < 64) tickets[tid] = z;
+        const size_t stride = (size_t)gridDim.x * kHistNT;
+        for (size_t i = (size_t)blockIdx.x * kHistNT + (size_t)tid; i < status_vecs; i += stride) status[i] = z;
+    }
     for (uint32_t i = (uint32_t)tid; i < total_bins; i += kHistNT) hist[i] = 0u;
     __syncthreads();
 
@@ -122,32 +132,61 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
                 off += joint_bins(desc.nbits[p]);
             }
         };
-        // 4 vectors at once.  Per pass: if every element of every active lane falls into one bin (constant /
-        // sorted input) one lane adds the total instead of 64 lanes serialising on one LDS word; the check is
-        // ~1 VALU per atomic it guards.
+        // 4 vectors at once.  Low-entropy guard: if, for a pass, every element of every active lane falls into one
+        // bin (constant / sorted / few-bit input) one lane adds the total instead of 64 lanes serialising on one
+        // LDS word.  The test is shared by all passes: `diff` ORs together key ^ (first lane's first key) over the
+        // lane's elements (2 VALU per key), and pass p is uniform iff no lane has a diff bit inside p's bin bits.
+        // It only runs when a one-key-per-lane screen finds a pass that might be uniform (never, on random keys).
+        typedef typename std::conditional<sizeof(E) == 8, uint64_t, uint32_t>::type K;
         auto bump4 = [&](const auto& a, const auto& b, const auto& c, const auto& d4) {
             constexpr int V = 16 / (int)sizeof(E);
-            uint32_t off = 0u;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                uint32_t bins[4 * V];
+            K f0;
+            if constexpr (sizeof(E) == 8) {
+                const uint64_t k0 = (uint64_t)a.v[0];
+                f0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(k0 >> 32)) << 32) |
+                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)k0);
+            } else {
+                f0 = (K)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a.v[0]);
+            }
+            auto mask_of = [&](int p) -> K {
+                const int sb = desc.start_bit[p];
+                const int nb = desc.nbits[p];
+                return (p == 0) ? (K)((1u << nb) - 1u) : ((K)((1u << (nb + 4)) - 1u) << (sb - 4));
+            };
+            auto plain = [&](int p, uint32_t off) {
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    bins[4 * k + 0] = bin_of(a.v[k], p);
-                    bins[4 * k + 1] = bin_of(b.v[k], p);
-                    bins[4 * k + 2] = bin_of(c.v[k], p);
-                    bins[4 * k + 3] = bin_of(d4.v[k], p);
+                    atomicAdd(&hist[off + bin_of(a.v[k], p)], 1u);
+                    atomicAdd(&hist[off + bin_of(b.v[k], p)], 1u);
+                    atomicAdd(&hist[off + bin_of(c.v[k], p)], 1u);
+                    atomicAdd(&hist[off + bin_of(d4.v[k], p)], 1u);
                 }
-                const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)bins[0]);
-                bool same = true;
+            };
+            // cheap screen on one key per lane: only if some pass looks uniform there is the full test worth running
+            const K d0 = (K)a.v[0] ^ f0;
+            bool maybe = false;
 #pragma unroll
-                for (int k = 0; k < 4 * V; ++k) same &= bins[k] == b0;
-                if (__all(same)) {
+            for (int p = 0; p < P; ++p) maybe |= __all((d0 & mask_of(p)) == 0);
+            uint32_t off = 0u;
+            if (!maybe) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    plain(p, off);
+                    off += joint_bins(desc.nbits[p]);
+                }
+                return;
+            }
+            K diff = 0;
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                diff |= ((K)a.v[k] ^ f0) | ((K)b.v[k] ^ f0) | ((K)c.v[k] ^ f0) | ((K)d4.v[k] ^ f0);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (__all((diff & mask_of(p)) == 0)) {
                     const uint64_t act = __ballot(true);   // the last iteration runs with some lanes off
-                    if (mbcnt64(act) == 0u) atomicAdd(&hist[off + b0], (uint32_t)(4 * V * __popcll(act)));
+                    if (mbcnt64(act) == 0u) atomicAdd(&hist[off + bin_of((E)f0, p)], (uint32_t)(4 * V * __popcll(act)));
                 } else {
-#pragma unroll
-                    for (int k = 0; k < 4 * V; ++k) atomicAdd(&hist[off + bins[k]], 1u);
+                    plain(p, off);
                 }
                 off += joint_bins(desc.nbits[p]);
             }

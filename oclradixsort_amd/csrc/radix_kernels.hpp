@@ -417,16 +417,19 @@ __global__ __launch_bounds__(NT) void radix_count_kernel(const E* __restrict__ s
         auto bump4 = [&](const auto& a, const auto& b, const auto& c, const auto& d4) {
             constexpr int V = 16 / (int)sizeof(E);
             if (NBITS > 4) {
-                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)digit_of<NBITS>(a.v[0], start_bit));
-                bool same = true;
+                const uint32_t da = digit_of<NBITS>(a.v[0], start_bit);
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)da);
+                if (__all(da == d0)) {   // one-key-per-lane screen: the full test below runs only when it might succeed
+                    bool same = true;
 #pragma unroll
-                for (int k = 0; k < V; ++k)
-                    same &= (digit_of<NBITS>(a.v[k], start_bit) == d0) & (digit_of<NBITS>(b.v[k], start_bit) == d0) &
-                            (digit_of<NBITS>(c.v[k], start_bit) == d0) & (digit_of<NBITS>(d4.v[k], start_bit) == d0);
-                if (__all(same)) {
-                    const uint64_t act = __ballot(true);
-                    if (mbcnt64(act) == 0u) atomicAdd(&hist[w * BINS + d0], (uint32_t)(4 * V * __popcll(act)));
-                    return;
+                    for (int k = 0; k < V; ++k)
+                        same &= (digit_of<NBITS>(a.v[k], start_bit) == d0) & (digit_of<NBITS>(b.v[k], start_bit) == d0) &
+                                (digit_of<NBITS>(c.v[k], start_bit) == d0) & (digit_of<NBITS>(d4.v[k], start_bit) == d0);
+                    if (__all(same)) {
+                        const uint64_t act = __ballot(true);
+                        if (mbcnt64(act) == 0u) atomicAdd(&hist[w * BINS + d0], (uint32_t)(4 * V * __popcll(act)));
+                        return;
+                    }
                 }
             }
 #pragma unroll
