@@ -112,6 +112,7 @@ struct Device {
     virtual void copyD2D(void* dst, const void* src, u64 bytes) const = 0;
     virtual void clearBytes(void* p, u64 bytes) const = 0;
     virtual void fillU32(void* p, unsigned int pattern, u64 count) const = 0;
+    virtual void fillPattern(void* p, const void* pattern, int patternBytes, u64 count) const = 0;   // 4, 8 or 16 bytes
     virtual void* mapBytes(void* p, u64 bytes) const = 0;
     virtual void unmapBytes(void* p, void* host, u64 bytes) const = 0;
     // the C-ABI handle behind a TYPE_CL device (0 for TYPE_HOST): what Pprims hands to adlhip_*
@@ -187,6 +188,10 @@ struct DeviceHip : public Device {
     void copyD2D(void* dst, const void* src, u64 bytes) const { ADLASSERT(adlhip_memcpy_d2d(m_hip, dst, src, (size_t)bytes) == 0); }
     void clearBytes(void* p, u64 bytes) const { ADLASSERT(adlhip_memset(m_hip, p, 0, (size_t)bytes) == 0); }
     void fillU32(void* p, unsigned int pattern, u64 count) const { ADLASSERT(adlhip_fill_u32(m_hip, p, pattern, (size_t)count) == 0); }
+    void fillPattern(void* p, const void* pattern, int patternBytes, u64 count) const
+    {
+        ADLASSERT(adlhip_fill_pattern(m_hip, p, pattern, (size_t)patternBytes, (size_t)count) == 0);
+    }
     void* mapBytes(void* p, u64 bytes) const
     {
         void* h = 0;
@@ -223,6 +228,10 @@ struct DeviceHost : public Device {
     void fillU32(void* p, unsigned int pattern, u64 count) const
     {
         for (u64 i = 0; i < count; ++i) ((unsigned int*)p)[i] = pattern;
+    }
+    void fillPattern(void* p, const void* pattern, int patternBytes, u64 count) const
+    {
+        for (u64 i = 0; i < count; ++i) memcpy((char*)p + i * patternBytes, pattern, patternBytes);
     }
     void* mapBytes(void* p, u64) const { return p; }        // AdlHost.inl:45-47: getHostPtr is m_ptr
     void unmapBytes(void*, void*, u64) const {}
@@ -326,8 +335,9 @@ struct Buffer : public BufferBase {
     void clear() { m_device->clearBytes(m_ptr, m_size * sizeof(T)); }
     void fill(void* pattern, int patternSize)
     {
-        ADLASSERT(patternSize == 4);
-        m_device->fillU32(m_ptr, *(unsigned int*)pattern, m_size * sizeof(T) / 4);
+        ADLASSERT(patternSize == 4 || patternSize == 8 || patternSize == 16);
+        ADLASSERT((m_size * sizeof(T)) % patternSize == 0);
+        m_device->fillPattern(m_ptr, pattern, patternSize, m_size * sizeof(T) / patternSize);
     }
     // map / unmap (Adl.inl:317-329): contents valid after waitForCompletion; writes reach the device
     // after returnHostPtr + waitForCompletion

@@ -1,6 +1,6 @@
 // Tahoe/Math/Math.h -- the handful of scalar typedefs / helpers the sort path uses.
 // Reference: Tahoe/Math/Math.h:19 (NEXTMULTIPLEOF), :53-60 (nextPowerOf2), :90-93 (u8..u64),
-// :175-188 (uint2), :230-242 (min2/max2), :324-330 (swap2).  The renderer's float/matrix math in the
+// :95-112 (float4, as data), :175-188 (uint2), :230-242 (min2/max2), :324-330 (swap2).  The renderer's float/matrix math in the
 // reference header is out of scope (SURVEY.md section 2.1 #9b).
 #pragma once
 #include <stddef.h>
@@ -24,6 +24,7 @@ struct uint2 { u32 x, y; };
 struct int2 { int x, y; };
 struct uint4 { u32 x, y, z, w; };
 struct int4 { int x, y, z, w; };
+struct alignas(16) float4 { float x, y, z, w; };   // Math.h:95-112 (16-byte aligned; only moved around here, never computed on)
 
 template <typename T> inline T max2(const T& a, const T& b) { return a > b ? a : b; }
 template <typename T> inline T min2(const T& a, const T& b) { return a < b ? a : b; }

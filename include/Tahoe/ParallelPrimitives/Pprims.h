@@ -4,6 +4,7 @@
 //   radixSort {u32 key, u32 value} pairs, stable                     (reference Pprims.h:38)
 //   radixSort u32 keys                                               (reference Pprims.h:41)
 //   radixSort u64 keys                                               (new: BASELINE config #5)
+//   copy / fill                                                      (reference Pprims.cpp:31-120, commented out there)
 // Same argument meaning; differences, all supersets: any n >= 0 (the reference needs n % 256 == 0 for
 // keys), scan has no 1,048,576-element limit, sortBits < 32 also works on 64-bit keys up to 64.
 // Device work is enqueued and the call returns (no sync), as in the reference's GPU branches.
@@ -34,6 +35,14 @@ public:
         R32SORT_ELEMENTS_PER_WORK_ITEM = (256 / R32SORT_WG_SIZE),
         R32SORT_BITS_PER_PASS = 4,      // the reference's digit width; select with adlhip "sort.digit_bits"
     };
+
+    // copy / fill (Pprims.cpp:31-120 -- present but commented out in the reference, with CopyIntKernel / CopyF4Kernel /
+    // FillIntKernel / FillU32Kernel / FillF4Kernel of ClKernels/PprimsKernels.cl): first n elements, enqueued
+    void copy(const adl::Device* device, adl::Buffer<int>& dst, const adl::Buffer<int>& src, int n);
+    void copy(const adl::Device* device, adl::Buffer<float4>& dst, const adl::Buffer<float4>& src, int n);
+    void fill(const adl::Device* device, adl::Buffer<int>& dst, int src, int n);
+    void fill(const adl::Device* device, adl::Buffer<u32>& dst, u32 src, int n);
+    void fill(const adl::Device* device, adl::Buffer<float4>& dst, const float4& src, int n);
 
     void scan(const adl::Device* device, adl::Buffer<int>& dst, const adl::Buffer<int>& src, int n, u32* sumOut = 0);
 

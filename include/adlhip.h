@@ -97,6 +97,10 @@ int adlhip_memcpy_d2d(adlhip_device* dev, void* dst_dev, const void* src_dev, si
 /* Buffer::clear / fill -- Adl/Adl.inl:305-315, AdlCL.inl:512-542 (byte-wise / 4-byte pattern). */
 int adlhip_memset(adlhip_device* dev, void* dptr, int byte_value, size_t bytes);
 int adlhip_fill_u32(adlhip_device* dev, void* dptr, uint32_t pattern, size_t count);
+/* Pprims::fill(int | u32 | float4) -- Tahoe/ParallelPrimitives/Pprims.cpp:69-120 (FillIntKernel / FillU32Kernel /
+ * FillF4Kernel, commented out in the reference): `count` copies of a 4-, 8- or 16-byte pattern read from host
+ * memory at call time.  dptr must be aligned to pattern_bytes. */
+int adlhip_fill_pattern(adlhip_device* dev, void* dptr, const void* pattern, size_t pattern_bytes, size_t count);
 
 /* Buffer::getHostPtr / returnHostPtr -- Adl/Adl.inl:317-329, AdlCL.inl:544-565 (non-blocking
  * clEnqueueMapBuffer READ|WRITE / clEnqueueUnmapMemObject).  adlhip_map enqueues a device->pinned-host

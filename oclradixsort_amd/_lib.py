@@ -52,6 +52,7 @@ SIGNATURES = {
     "adlhip_memcpy_d2d": (_I, [_VP, _VP, _VP, _SZ]),
     "adlhip_memset": (_I, [_VP, _VP, _I, _SZ]),
     "adlhip_fill_u32": (_I, [_VP, _VP, ctypes.c_uint32, _SZ]),
+    "adlhip_fill_pattern": (_I, [_VP, _VP, _VP, _SZ, _SZ]),
     "adlhip_map": (_I, [_VP, _VP, _SZ, c_void_pp]),
     "adlhip_unmap": (_I, [_VP, _VP, _VP, _SZ]),
     "adlhip_radix_sort_scratch_bytes": (_I, [_VP, _I, _SZ, c_size_p, c_size_p]),

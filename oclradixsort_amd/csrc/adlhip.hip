@@ -831,6 +831,48 @@ int adlhip_fill_u32(adlhip_device* d, void* dptr, uint32_t pattern, size_t count
     });
 }
 
+int adlhip_fill_pattern(adlhip_device* d, void* dptr, const void* pattern, size_t pattern_bytes, size_t count)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (pattern_bytes != 4 && pattern_bytes != 8 && pattern_bytes != 16) return fail("fill: pattern of %zu bytes (4, 8 or 16)", pattern_bytes);
+    if (count == 0) return ADLHIP_SUCCESS;
+    if (!dptr || !pattern) return fail("fill: null pointer");
+    if (reinterpret_cast<uintptr_t>(dptr) % pattern_bytes) return fail("fill: destination not aligned to the pattern size");
+    if (pattern_bytes == 4) {
+        uint32_t v;
+        memcpy(&v, pattern, 4);
+        return adlhip_fill_u32(d, dptr, v, count);
+    }
+    uint4 p16;
+    uint2 p8 = make_uint2(0u, 0u);
+    uint2* tail = nullptr;
+    uint4* dst = reinterpret_cast<uint4*>(dptr);
+    size_t vecs = count;
+    if (pattern_bytes == 16) {
+        memcpy(&p16, pattern, 16);
+    } else {
+        memcpy(&p8, pattern, 8);
+        p16 = make_uint4(p8.x, p8.y, p8.x, p8.y);
+        uint2* d8 = reinterpret_cast<uint2*>(dptr);
+        size_t c = count;
+        if (reinterpret_cast<uintptr_t>(dptr) & 8u) {   // leading odd element: written through the tail slot of a first launch
+            int rc = launch(d, "fill_pattern", [&] {
+                hipLaunchKernelGGL(adlhip::fill_pattern16_kernel, dim3(1), dim3(256), 0, d->stream, (uint4*)nullptr, p16, (size_t)0, d8, p8);
+            });
+            if (rc) return rc;
+            ++d8;
+            if (--c == 0) return ADLHIP_SUCCESS;
+        }
+        dst = reinterpret_cast<uint4*>(d8);
+        vecs = c / 2;
+        if (c & 1) tail = d8 + (c - 1);
+    }
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((vecs + 255) / 256, (size_t)d->prop.multiProcessorCount * 8));
+    return launch(d, "fill_pattern", [&] {
+        hipLaunchKernelGGL(adlhip::fill_pattern16_kernel, dim3(grid), dim3(256), 0, d->stream, dst, p16, vecs, tail, p8);
+    });
+}
+
 int adlhip_map(adlhip_device* d, void* dptr, size_t bytes, void** hptr)
 {
     if (bind(d)) return ADLHIP_FAILURE;

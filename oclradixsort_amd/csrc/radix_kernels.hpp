@@ -786,6 +786,16 @@ __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ ds
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[i] = pattern;
 }
 
+// count copies of a 16-byte pattern (8-byte patterns are doubled by the host: count is then in 16-byte units
+// plus an optional 8-byte tail written by thread 0)
+__global__ __launch_bounds__(256) void fill_pattern16_kernel(uint4* __restrict__ dst, uint4 pattern, size_t count,
+                                                             uint2* __restrict__ tail8, uint2 tail_pattern)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[i] = pattern;
+    if (tail8 && blockIdx.x == 0 && threadIdx.x == 0) *tail8 = tail_pattern;
+}
+
 // Device self-test for the RANK == 1 path: do returning DS atomics of one wave-instruction resolve
 // colliding lanes in ascending lane order, and do successive instructions of a wave apply in order?
 // Compares ds_add_rtn ranks with ballot/mbcnt ranks over pseudo-random digits for 1, 2, 16 and 256

@@ -108,6 +108,27 @@ class Pprims:
         assert inout.dtype == np.uint64
         self._sort(device, ELEM_U64, _lib.load().adlhip_radix_sort_u64, inout, n, sortBits)
 
+    def copy(self, device, dst, src, n):
+        """Pprims::copy (Pprims.cpp:31-67, commented out in the reference): first n elements of src -> dst."""
+        if device is None:
+            raise AdlHipError("copy needs a device")
+        assert dst.dtype == src.dtype and n <= dst.getSize() and n <= src.getSize()
+        if n > 0:
+            check(_lib.load().adlhip_memcpy_d2d(device._h, dst.ptr(), src.ptr(), int(n) * dst.dtype.itemsize), "copy")
+
+    def fill(self, device, dst, value, n):
+        """Pprims::fill (Pprims.cpp:69-120, commented out in the reference): n copies of one element.  `value`
+        is anything numpy can turn into ONE element of dst.dtype (4-, 8- or 16-byte element types)."""
+        if device is None:
+            raise AdlHipError("fill needs a device")
+        assert n <= dst.getSize()
+        pat = np.array(value, dtype=dst.dtype).reshape(1)
+        if pat.dtype.itemsize not in (4, 8, 16):
+            raise AdlHipError("fill: element size %d (4, 8 or 16 bytes)" % pat.dtype.itemsize)
+        if n > 0:
+            check(_lib.load().adlhip_fill_pattern(device._h, dst.ptr(), pat.ctypes.data_as(ctypes.c_void_p),
+                                                  pat.dtype.itemsize, int(n)), "fill")
+
     def scan(self, device, dst, src, n, sumOut=None):
         """Exclusive prefix sum.  sumOut: optional 1-element uint32 numpy array that receives the grand
         total once the caller has synchronised (Pprims.cpp:164-167 reads it back non-blocking too)."""

@@ -31,6 +31,30 @@ void Pprims::reserve(const adl::Device* device, size_t tmpBytes, size_t workByte
     if (m_work->getSize() < workBytes) m_work->setSize(workBytes);
 }
 
+// copy / fill: the device does the work whatever its type (a TYPE_HOST device's hooks are memcpy / loops, which is
+// what the reference's `device == 0` branches do, Pprims.cpp:34-38, :71-75)
+template <typename T>
+static void copyN(const adl::Device* device, adl::Buffer<T>& dst, const adl::Buffer<T>& src, int n)
+{
+    ADLASSERT(device != 0 && n >= 0);
+    ADLASSERT((adl::u64)n <= dst.getSize() && (adl::u64)n <= src.getSize());
+    if (n > 0) device->copyD2D(dst.m_ptr, src.m_ptr, (adl::u64)n * sizeof(T));
+}
+
+template <typename T>
+static void fillN(const adl::Device* device, adl::Buffer<T>& dst, const T& src, int n)
+{
+    ADLASSERT(device != 0 && n >= 0);
+    ADLASSERT((adl::u64)n <= dst.getSize());
+    if (n > 0) device->fillPattern(dst.m_ptr, &src, (int)sizeof(T), (adl::u64)n);
+}
+
+void Pprims::copy(const adl::Device* device, adl::Buffer<int>& dst, const adl::Buffer<int>& src, int n) { copyN(device, dst, src, n); }
+void Pprims::copy(const adl::Device* device, adl::Buffer<float4>& dst, const adl::Buffer<float4>& src, int n) { copyN(device, dst, src, n); }
+void Pprims::fill(const adl::Device* device, adl::Buffer<int>& dst, int src, int n) { fillN(device, dst, src, n); }
+void Pprims::fill(const adl::Device* device, adl::Buffer<u32>& dst, u32 src, int n) { fillN(device, dst, src, n); }
+void Pprims::fill(const adl::Device* device, adl::Buffer<float4>& dst, const float4& src, int n) { fillN(device, dst, src, n); }
+
 static inline bool enableSortOnDevice(const adl::Device* device)
 {
     // Pprims.cpp:189-198: only a GPU behind TYPE_CL sorts on the device

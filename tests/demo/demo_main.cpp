@@ -144,6 +144,46 @@ void demoScan(Device* d, Pprims& p)
     printf("[       %s ] Demo.Scan (%.0f ms)\n", g_failed > before ? "FAIL" : "OK", now_ms() - t0);
 }
 
+// Pprims::fill / copy (commented out in the reference, Pprims.cpp:31-120): int, u32 and float4 elements, odd counts,
+// and everything past n untouched.
+void demoFillCopy(Device* d, Pprims& p)
+{
+    printf("[ RUN      ] Demo.FillCopy\n");
+    const double t0 = now_ms();
+    const int before = g_failed;
+    const int sizes[] = {1, 2, 3, 255, 1024, 100003, 1 << 20};
+    for (int n : sizes) {
+        const int cap = n + 5;
+        Buffer<int> bi(d, cap), ci(d, cap);
+        Buffer<u32> bu(d, cap);
+        Buffer<float4> bf(d, cap), cf(d, cap);
+        bi.clear(); ci.clear(); bu.clear(); bf.clear(); cf.clear();
+        float4 pat;
+        pat.x = 1.5f; pat.y = -2.25f; pat.z = 3.f; pat.w = (float)n;
+        p.fill(d, bi, -7 - n, n);
+        p.fill(d, bu, 0xC0FFEE00u + (u32)n, n);
+        p.fill(d, bf, pat, n);
+        p.copy(d, ci, bi, n);
+        p.copy(d, cf, bf, n);
+        int* hi = ci.getHostPtr(cap);
+        u32* hu = bu.getHostPtr(cap);
+        float4* hf = cf.getHostPtr(cap);
+        DeviceUtils::waitForCompletion(d);
+        bool ok = true;
+        for (int i = 0; i < cap; ++i) {
+            const bool in = i < n;
+            ok &= hi[i] == (in ? -7 - n : 0);
+            ok &= hu[i] == (in ? 0xC0FFEE00u + (u32)n : 0u);
+            ok &= hf[i].x == (in ? pat.x : 0.f) && hf[i].y == (in ? pat.y : 0.f) && hf[i].z == (in ? pat.z : 0.f) &&
+                  hf[i].w == (in ? pat.w : 0.f);
+        }
+        check(ok, "fill/copy result", n);
+        ci.returnHostPtr(hi); bu.returnHostPtr(hu); cf.returnHostPtr(hf);
+        DeviceUtils::waitForCompletion(d);
+    }
+    printf("[       %s ] Demo.FillCopy (%.0f ms)\n", g_failed > before ? "FAIL" : "OK", now_ms() - t0);
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -165,6 +205,7 @@ int main(int argc, char** argv)
         Pprims p;
         demoSort32(d, p);
         demoSortKeyValue(d, p);
+        demoFillCopy(d, p);
         if (!host) demoScan(d, p);   // scan has no host path in the reference either (Pprims.cpp:124-127)
     }
     DeviceUtils::deallocate(d);

@@ -27,6 +27,7 @@ def test_demo_on_adl_host_cpu_path(built):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "PASSED: 0 failed checks" in r.stdout
     assert r.stdout.count("test ") == 22          # 11 sizes x 2 primitives
+    assert re.search(r"OK \] Demo\.FillCopy", r.stdout)   # Pprims::fill / copy on the host device
     assert "1050.0K" in r.stdout                  # the key-value sizes really are 2*prev+13 (README.md:96-106)
 
 
@@ -66,6 +67,7 @@ def test_demo_on_the_hip_device(built):
     assert "PASSED: 0 failed checks" in r.stdout
     assert r.stdout.count("test ") == 33          # 11 sizes x 3 primitives, Scan includes 1024K
     assert re.search(r"OK \] Demo\.Scan", r.stdout)
+    assert re.search(r"OK \] Demo\.FillCopy", r.stdout)
 
 
 @pytest.mark.gpu

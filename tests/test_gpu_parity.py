@@ -6,6 +6,7 @@ Mirrors the reference's test (UnitTest/main.cpp:40-56, 88-213: Demo.Sort32 / Dem
 Demo.Scan over 11 doubling sizes with srand(123) data) and adds what it lacks:
 low-entropy keys, ragged n, partial sortBits, n = 0, scan >= 1M, scratch reuse, 64-bit keys.
 """
+import ctypes
 import json
 import os
 
@@ -13,7 +14,8 @@ import numpy as np
 import pytest
 
 import oracle
-from oclradixsort_amd import AdlHipError, Buffer, DeviceUtils, Pprims, Stopwatch
+from oclradixsort_amd import AdlHipError, Buffer, DeviceUtils, Pprims, Stopwatch, _lib
+from oclradixsort_amd._lib import check
 
 pytestmark = pytest.mark.gpu
 
@@ -520,3 +522,39 @@ def test_soa_key_value_sort(dev, pp, algo):
             assert np.array_equal(gk, (want & np.uint64(0xffffffff)).astype(np.uint32)), (n, bits)
             assert np.array_equal(gv, (want >> np.uint64(32)).astype(np.uint32)), (n, bits)
             kb.release(); vb.release()
+
+
+# ---------------------------------------------------------------------------------------------
+# Pprims::fill / copy (commented out in the reference, Pprims.cpp:31-120)
+# ---------------------------------------------------------------------------------------------
+def test_fill_and_copy_primitives(dev, pp):
+    f4 = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4")])     # Tahoe::float4 as 16 plain bytes
+    cases = [(np.uint32, 0xC0FFEE01), (np.int32, -12345), (np.uint64, 0x0123456789ABCDEF), (f4, (1.5, -2.25, 3.0, 4.0))]
+    for dtype, value in cases:
+        for n in (0, 1, 2, 3, 255, 4097, 100003, (1 << 22) + 1):
+            cap = n + 7
+            a, b = Buffer(dev, cap, dtype), Buffer(dev, cap, dtype)
+            a.clear(); b.clear()
+            pp.fill(dev, a, value, n)
+            pp.copy(dev, b, a, n)
+            want = np.zeros(cap, dtype=dtype)
+            want[:n] = np.array(value, dtype=dtype)
+            assert a.toHost().tobytes() == want.tobytes(), (dtype, n)
+            assert b.toHost().tobytes() == want.tobytes(), (dtype, n)
+            a.release(); b.release()
+    # 8-byte pattern at an address that is 8- but not 16-byte aligned (the odd leading element), odd and even counts
+    lib = _lib.load()
+    buf = Buffer(dev, 64, np.uint64)
+    pat = np.array([0xFEEDFACECAFEBEEF], dtype=np.uint64)
+    for first, cnt in ((1, 1), (1, 2), (1, 5), (3, 6), (2, 7)):
+        buf.clear()
+        check(lib.adlhip_fill_pattern(dev._h, buf.ptr(first), pat.ctypes.data_as(ctypes.c_void_p), 8, cnt), "fill_pattern")
+        got = buf.toHost()
+        want = np.zeros(64, dtype=np.uint64)
+        want[first:first + cnt] = pat[0]
+        assert np.array_equal(got, want), (first, cnt)
+    # loud failures: unsupported pattern size, misaligned destination
+    assert lib.adlhip_fill_pattern(dev._h, buf.ptr(), pat.ctypes.data_as(ctypes.c_void_p), 3, 4) != 0
+    assert lib.adlhip_fill_pattern(dev._h, ctypes.c_void_p(buf.m_ptr + 4), pat.ctypes.data_as(ctypes.c_void_p), 8, 1) != 0
+    assert b"fill" in lib.adlhip_last_error()
+    buf.release()
