@@ -132,22 +132,19 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
                 off += joint_bins(desc.nbits[p]);
             }
         };
-        // 4 vectors at once.  Low-entropy guard: if, for a pass, every element of every active lane falls into one
-        // bin (constant / sorted / few-bit input) one lane adds the total instead of 64 lanes serialising on one
-        // LDS word.  The test is shared by all passes: `diff` ORs together key ^ (first lane's first key) over the
-        // lane's elements (2 VALU per key), and pass p is uniform iff no lane has a diff bit inside p's bin bits.
-        // It only runs when a one-key-per-lane screen finds a pass that might be uniform (never, on random keys).
+        // 4 vectors at once.  Guards against same-address LDS atomics (64 lanes on one word serialise; sorted input
+        // made this kernel 4.7x slower), decided per pass from a screen on ONE key per lane -- the number of lanes
+        // whose bin differs from their left neighbour's ("run heads"; the first lane of each row of 16 always counts):
+        //   * 4 heads and the exact test agrees -> the whole wave is in one bin: one lane adds the total.  The exact
+        //     test is shared by all passes: `diff` ORs key ^ (first lane's first key) over the lane's 16 keys, and
+        //     pass p is uniform iff no lane has a diff bit inside p's bin bits;
+        //   * <= 16 heads (sorted / clustered input) -> run-aggregated adds: per instruction every run of equal
+        //     neighbouring lanes is added once, by its head, with the run length as the addend;
+        //   * otherwise (always, on random keys) plain atomics.  The screen costs ~5 instructions per pass and 16 keys.
         typedef typename std::conditional<sizeof(E) == 8, uint64_t, uint32_t>::type K;
+        const int lane = tid & 63;
         auto bump4 = [&](const auto& a, const auto& b, const auto& c, const auto& d4) {
             constexpr int V = 16 / (int)sizeof(E);
-            K f0;
-            if constexpr (sizeof(E) == 8) {
-                const uint64_t k0 = (uint64_t)a.v[0];
-                f0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(k0 >> 32)) << 32) |
-                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)k0);
-            } else {
-                f0 = (K)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a.v[0]);
-            }
             auto mask_of = [&](int p) -> K {
                 const int sb = desc.start_bit[p];
                 const int nb = desc.nbits[p];
@@ -162,29 +159,56 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
                     atomicAdd(&hist[off + bin_of(d4.v[k], p)], 1u);
                 }
             };
-            // cheap screen on one key per lane: only if some pass looks uniform there is the full test worth running
-            const K d0 = (K)a.v[0] ^ f0;
-            bool maybe = false;
+            // left neighbour's bin (row_shr:1); the first lane of a row keeps ~bin, i.e. always starts a run
+            auto left_of = [](uint32_t bin) -> uint32_t {
+                return (uint32_t)__builtin_amdgcn_update_dpp((int)~bin, (int)bin, 0x111, 0xf, 0xf, false);
+            };
+            auto add_runs = [&](uint32_t* h, uint32_t bin) {   // all 64 lanes active
+                const bool head = left_of(bin) != bin;
+                const uint64_t heads = __ballot(head);
+                // distance to the next head above this lane (bit 63 - lane = a virtual head at lane 64)
+                const uint64_t above = ((heads >> 1) >> lane) | (1ull << (63 - lane));
+                const uint32_t len = (uint32_t)__builtin_ctzll(above) + 1u;
+                if (head) atomicAdd(&h[bin], len);
+            };
+            auto runs = [&](int p, uint32_t off) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) maybe |= __all((d0 & mask_of(p)) == 0);
-            uint32_t off = 0u;
-            if (!maybe) {
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    plain(p, off);
-                    off += joint_bins(desc.nbits[p]);
+                for (int k = 0; k < V; ++k) {
+                    add_runs(hist + off, bin_of(a.v[k], p));
+                    add_runs(hist + off, bin_of(b.v[k], p));
+                    add_runs(hist + off, bin_of(c.v[k], p));
+                    add_runs(hist + off, bin_of(d4.v[k], p));
                 }
-                return;
-            }
-            K diff = 0;
-#pragma unroll
-            for (int k = 0; k < V; ++k)
-                diff |= ((K)a.v[k] ^ f0) | ((K)b.v[k] ^ f0) | ((K)c.v[k] ^ f0) | ((K)d4.v[k] ^ f0);
+            };
+            const bool full = __ballot(true) == ~0ull;   // the last iteration may run with some lanes off: plain only
+            uint32_t nheads[P];
+            bool any_uniform = false;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                if (__all((diff & mask_of(p)) == 0)) {
-                    const uint64_t act = __ballot(true);   // the last iteration runs with some lanes off
-                    if (mbcnt64(act) == 0u) atomicAdd(&hist[off + bin_of((E)f0, p)], (uint32_t)(4 * V * __popcll(act)));
+                const uint32_t b0 = bin_of(a.v[0], p);
+                nheads[p] = full ? (uint32_t)__popcll(__ballot(left_of(b0) != b0)) : 64u;
+                any_uniform |= nheads[p] == 4u;
+            }
+            K f0 = 0, diff = 0;
+            if (any_uniform) {
+                if constexpr (sizeof(E) == 8) {
+                    const uint64_t k0 = (uint64_t)a.v[0];
+                    f0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(k0 >> 32)) << 32) |
+                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)k0);
+                } else {
+                    f0 = (K)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a.v[0]);
+                }
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+                    diff |= ((K)a.v[k] ^ f0) | ((K)b.v[k] ^ f0) | ((K)c.v[k] ^ f0) | ((K)d4.v[k] ^ f0);
+            }
+            uint32_t off = 0u;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (nheads[p] == 4u && __all((diff & mask_of(p)) == 0)) {
+                    if (lane == 0) atomicAdd(&hist[off + bin_of((E)f0, p)], (uint32_t)(4 * V * 64));
+                } else if (nheads[p] <= 16u) {
+                    runs(p, off);
                 } else {
                     plain(p, off);
                 }

@@ -31,5 +31,11 @@ for kind in ("uniform", "sorted", "reverse", "all_equal", "16_values", "low_byte
             sw = Stopwatch(d); sw.start(); p.radixSort(d, work, n); sw.stop()
             best = min(best, sw.getMs())
         row.append("a%d/r%d %.3f" % (algo, rank, best))
+        if "--profile" in sys.argv and rank == 1:   # per-kernel breakdown of one more sort
+            work.write(base, n); DeviceUtils.waitForCompletion(d)
+            d.toggleProfiling(True); d.profile(reset=True)
+            p.radixSort(d, work, n); DeviceUtils.waitForCompletion(d)
+            prof = d.profile(reset=True); d.toggleProfiling(False)
+            row.append("[" + " ".join("%s=%.3f" % (k, ms / c) for k, (c, ms) in prof.items()) + "]")
     print("%-12s %s" % (kind, "   ".join(row)), flush=True)
 base.release(); work.release(); p.close(); DeviceUtils.deallocate(d)
