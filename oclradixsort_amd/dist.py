@@ -13,10 +13,20 @@ log2(G) bits equal g.  Per sort:
 Concatenating the ranks' outputs in rank order is the globally sorted array.  Receive buffers are
 sized from the exchanged counts, never from n/G.
 
+Two drivers over the same steps:
+  * ShardedRadixSort.sort(keys)          -- one batch, steps 1-4 back to back on the caller's stream;
+  * ShardedRadixSort.sort_stream(batches) -- a stream of independent batches, two-stage pipeline: steps
+    1-3 of batch i+1 ("exchange stage", its own HIP stream) run while step 4 of batch i ("sort stage",
+    a second HIP stream) runs.  The exchange is xGMI-bound and leaves HBM and most CUs idle, the local
+    sort is HBM-bound and leaves xGMI idle, so the two overlap almost fully; the only host sync (the
+    count matrix of batch i+1) is taken AFTER batch i's local sort has been enqueued.
+
 The device work is delegated to a `backend` object so that the host logic above (split arithmetic,
-exchange, ordering) can be exercised on CPU with gloo in the tests.  The product backend is
-HipBackend; there is no CPU backend in this package.
+exchange, ordering, pipelining) can be exercised on CPU with gloo in the tests.  The product backend
+is HipBackend; there is no CPU backend in this package.
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -24,68 +34,196 @@ import torch.distributed as dist
 from . import _lib
 from ._lib import check
 from .adl import Buffer, Config, DeviceUtils
-from .pprims import Pprims
+from .pprims import ELEM_U32, Pprims
+
+
+class _Stage:
+    """One pipeline stage on one GPU: a HIP stream (torch's) + an adlhip device bound to it + the
+    Pprims object that owns the stage's sort scratch."""
+
+    def __init__(self, local_rank, stream):
+        self.stream = stream            # torch.cuda.Stream, or None = torch's current stream at construction
+        raw = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
+        self.device = DeviceUtils.allocate(cfg=Config(local_rank), stream=raw)
+        self.pprims = Pprims()
+        self.work = None                # partition scratch
+        self.reserved = 0               # keys the sort scratch has been sized for
+
+    def close(self):
+        self.pprims.close()
+        if self.work is not None:
+            self.work.release()
+            self.work = None
+        DeviceUtils.deallocate(self.device)
 
 
 class HipBackend:
     """Device half of the sharded sort on one MI355X: torch owns the memory, libadlhip.so does the work
-    on torch's current stream (so RCCL collectives and sort kernels are ordered without extra syncs)."""
+    on torch streams (so RCCL collectives and sort kernels are ordered by stream order and events,
+    never by host syncs).  Stages: `caller` (torch's current stream at construction; sort()),
+    `exchange` and `sorting` (two extra streams, created on first use; sort_stream())."""
+
+    pipeline_depth = 3      # receive slots: the caller may hold 2 results while the third slot is being filled
 
     def __init__(self, local_rank=0):
         import ctypes
         self._ct = ctypes
+        self.local_rank = local_rank
         torch.cuda.set_device(local_rank)
         self.torch_device = torch.device("cuda", local_rank)
-        stream = torch.cuda.current_stream().cuda_stream
-        self.device = DeviceUtils.allocate(cfg=Config(local_rank), stream=stream)
-        self.pprims = Pprims()
-        self._counts = None
-        self._work = None
+        self._caller = _Stage(local_rank, None)
+        self._exchange = None
+        self._sorting = None
+        self._cur = self._caller
+        self._params = {}
+        self._recv = {}
+        self._part = {}
+
+    # the caller-stream device doubles as the handle for knobs (bench.py: sort.algo, sort.digit_bits)
+    @property
+    def device(self):
+        return self._caller.device
+
+    @property
+    def pprims(self):
+        return self._caller.pprims
+
+    def setParam(self, name, value):
+        """Set a libadlhip knob on every stage (also on stages created later)."""
+        self._params[name] = int(value)
+        for st in (self._caller, self._exchange, self._sorting):
+            if st is not None:
+                st.device.setParam(name, value)
+
+    def _stage(self, which):
+        st = getattr(self, which)
+        if st is None:
+            st = _Stage(self.local_rank, torch.cuda.Stream(device=self.torch_device))
+            for k, v in self._params.items():
+                st.device.setParam(k, v)
+            setattr(self, which, st)
+        return st
 
     def close(self):
-        self.pprims.close()
-        if self._work is not None:
-            self._work.release()
-            self._work = None
-        DeviceUtils.deallocate(self.device)
+        torch.cuda.synchronize(self.torch_device)
+        self._recv.clear()
+        self._part.clear()
+        for st in (self._caller, self._exchange, self._sorting):
+            if st is not None:
+                st.close()
+        self._caller = self._exchange = self._sorting = None
 
+    # ---- pipeline plumbing (sort_stream) --------------------------------------------------------
+    @contextlib.contextmanager
+    def exchange_scope(self, after_caller=False):
+        """Work enqueued inside goes to the exchange stage's stream; with after_caller, after everything
+        the caller has enqueued so far on its own stream (the batch's keys, reads of earlier results)."""
+        st = self._stage("_exchange")
+        if after_caller:
+            st.stream.wait_stream(torch.cuda.current_stream(self.torch_device))
+        prev, self._cur = self._cur, st
+        try:
+            with torch.cuda.stream(st.stream):
+                yield
+        finally:
+            self._cur = prev
+
+    @contextlib.contextmanager
+    def sort_scope(self, after=None):
+        """Work enqueued inside goes to the sort stage's stream, after event `after`."""
+        st = self._stage("_sorting")
+        if after is not None:
+            st.stream.wait_event(after)
+        prev, self._cur = self._cur, st
+        try:
+            with torch.cuda.stream(st.stream):
+                yield
+        finally:
+            self._cur = prev
+
+    def event(self, timing=False):
+        """Record an event on the stream of the scope we are in."""
+        ev = torch.cuda.Event(enable_timing=timing)
+        ev.record(torch.cuda.current_stream(self.torch_device))
+        return ev
+
+    def wait(self, ev):
+        """The stream of the scope we are in waits for `ev` (device-side, the host does not block)."""
+        if ev is not None:
+            torch.cuda.current_stream(self.torch_device).wait_event(ev)
+
+    def _slot_buffer(self, pool, slot, n):
+        t = pool.get(slot)
+        if t is None or t.numel() < n:
+            # grow with headroom so that batch-to-batch jitter of the received count does not reallocate;
+            # the old tensor goes back to torch's allocator, which keeps it alive for the streams that used it
+            if t is not None:
+                for st in (self._exchange, self._sorting):
+                    if st is not None:
+                        t.record_stream(st.stream)
+            cap = int(n) + int(n) // 16 + 1024
+            t = torch.empty(cap, dtype=torch.int32, device=self.torch_device)
+            pool[slot] = t
+        return t[:n]
+
+    def recv_buffer(self, slot, n):
+        """Persistent receive buffer of pipeline slot `slot`, at least n keys (view of exactly n)."""
+        return self._slot_buffer(self._recv, slot, n)
+
+    def part_buffer(self, slot, n):
+        return self._slot_buffer(self._part, slot, n)
+
+    # ---- device work -----------------------------------------------------------------------------
     def empty(self, n):
         return torch.empty(int(n), dtype=torch.int32, device=self.torch_device)
 
-    def _wrap(self, t):
+    def _wrap(self, device, t):
         b = Buffer(dtype=np.uint32)
-        b.setRawPtr(self.device, t.data_ptr(), t.numel())
+        b.setRawPtr(device, t.data_ptr(), t.numel())
         return b
 
-    def partition_msb(self, keys, num_buckets):
+    def partition_msb(self, keys, num_buckets, out=None):
         """keys: int32 CUDA tensor holding u32 bit patterns.  Returns (partitioned tensor, int32 CUDA
-        tensor of num_buckets segment sizes)."""
+        tensor of num_buckets segment sizes).  Runs on the stage of the scope we are in."""
         ct = self._ct
+        st = self._cur
         n = keys.numel()
-        out = self.empty(n)
+        if out is None:
+            out = self.empty(n)
         counts = torch.zeros(num_buckets, dtype=torch.int32, device=self.torch_device)
         lib = _lib.load()
         tb = ct.c_size_t()
         wb = ct.c_size_t()
-        check(lib.adlhip_radix_sort_scratch_bytes(self.device._h, 0, n, ct.byref(tb), ct.byref(wb)), "scratch_bytes")
-        if self._work is None or self._work.getSize() < wb.value:
-            if self._work is not None:
-                self._work.release()
-            self._work = Buffer(self.device, wb.value, np.uint8)
-        check(lib.adlhip_partition_msb_u32(self.device._h, ct.c_void_p(keys.data_ptr()), ct.c_void_p(out.data_ptr()),
-                                           ct.c_void_p(counts.data_ptr()), self._work.ptr(), self._work.getSize(),
+        check(lib.adlhip_radix_sort_scratch_bytes(st.device._h, 0, n, ct.byref(tb), ct.byref(wb)), "scratch_bytes")
+        if st.work is None or st.work.getSize() < wb.value:
+            if st.work is not None:
+                DeviceUtils.waitForCompletion(st.device)
+                st.work.release()
+            st.work = Buffer(st.device, wb.value + wb.value // 8, np.uint8)
+        check(lib.adlhip_partition_msb_u32(st.device._h, ct.c_void_p(keys.data_ptr()), ct.c_void_p(out.data_ptr()),
+                                           ct.c_void_p(counts.data_ptr()), st.work.ptr(), st.work.getSize(),
                                            n, int(num_buckets)), "adlhip_partition_msb_u32")
         return out, counts
 
     def local_sort(self, keys):
-        """In-place ascending sort of an int32 CUDA tensor holding u32 bit patterns."""
-        if keys.numel():
-            self.pprims.radixSort(self.device, self._wrap(keys), keys.numel())
+        """In-place ascending sort of an int32 CUDA tensor holding u32 bit patterns, on the stage of the
+        scope we are in."""
+        n = keys.numel()
+        if n:
+            st = self._cur
+            if n > st.reserved:
+                # received counts jitter from batch to batch: size the scratch with headroom once instead of
+                # re-growing it (a device-wide sync + hipMalloc) whenever a slightly larger batch arrives
+                st.reserved = n + n // 16 + 1024
+                st.pprims.reserve(st.device, ELEM_U32, st.reserved)
+            st.pprims.radixSort(st.device, self._wrap(st.device, keys), n)
         return keys
 
 
 class ShardedRadixSort:
-    """Host logic of the MSB-bucket sharded sort.  `backend` supplies empty / partition_msb / local_sort."""
+    """Host logic of the MSB-bucket sharded sort.  `backend` supplies empty / partition_msb / local_sort
+    (and, for sort_stream, the pipeline plumbing: exchange_scope / sort_scope / event / wait /
+    recv_buffer / part_buffer / pipeline_depth)."""
 
     def __init__(self, backend, group=None):
         self.backend = backend
@@ -98,21 +236,88 @@ class ShardedRadixSort:
             raise ValueError("at most 256 ranks")
         self.last_splits = None
 
-    def sort(self, keys, force_exchange=False):
-        """keys: this rank's shard.  Returns this rank's slice of the globally sorted sequence
-        (all keys whose top log2(world) bits equal the rank, ascending).  force_exchange runs the
-        partition + collectives even with one rank (used to exercise the code path on a 1-GPU box)."""
+    def _splits(self, matrix):
+        """Count matrix (row r = rank r's send counts) -> (send_splits, recv_splits) of this rank.  The
+        .cpu() is the only host sync of a sort; it waits for the stream the matrix was gathered on."""
         G = self.world
-        if G == 1 and not (force_exchange and dist.is_initialized()):
-            return self.backend.local_sort(keys)
-        part, counts = self.backend.partition_msb(keys, G)
-        # one collective for all split sizes: row r of the matrix = rank r's send counts
-        matrix = torch.empty(G * G, dtype=counts.dtype, device=counts.device)
-        dist.all_gather_into_tensor(matrix, counts, group=self.group)
-        m = matrix.cpu().view(G, G)                      # the only host sync of the sort
+        m = matrix.cpu().view(G, G)
         send_splits = [int(x) for x in m[self.rank]]
         recv_splits = [int(x) for x in m[:, self.rank]]  # segments arrive in source-rank order
         self.last_splits = (send_splits, recv_splits)
-        recv = self.backend.empty(sum(recv_splits))
+        return send_splits, recv_splits
+
+    def sort(self, keys, force_exchange=False, marks=None):
+        """keys: this rank's shard.  Returns this rank's slice of the globally sorted sequence
+        (all keys whose top log2(world) bits equal the rank, ascending).  force_exchange runs the
+        partition + collectives even with one rank (used to exercise the code path on a 1-GPU box).
+        marks: optional list that receives five backend events (start, partitioned, counts known,
+        exchanged, sorted) for a per-stage breakdown."""
+        be = self.backend
+        G = self.world
+        if G == 1 and not (force_exchange and dist.is_initialized()):
+            return be.local_sort(keys)
+        mark = (lambda: marks.append(be.event(True))) if marks is not None else (lambda: None)
+        mark()
+        part, counts = be.partition_msb(keys, G)
+        mark()
+        # one collective for all split sizes: row r of the matrix = rank r's send counts
+        matrix = torch.empty(G * G, dtype=counts.dtype, device=counts.device)
+        dist.all_gather_into_tensor(matrix, counts, group=self.group)
+        send_splits, recv_splits = self._splits(matrix)
+        mark()
+        recv = be.empty(sum(recv_splits))
         dist.all_to_all_single(recv, part, recv_splits, send_splits, group=self.group)
-        return self.backend.local_sort(recv)
+        mark()
+        be.local_sort(recv)
+        mark()
+        return recv
+
+    def sort_stream(self, batches, force_exchange=False):
+        """Generator: feeds an iterable of independent batches (this rank's shard of each) through the
+        two-stage pipeline and yields, in order, this rank's slice of each batch's globally sorted
+        sequence.  Batch i+1's partition + exchange overlap batch i's local sort.
+
+        Every rank must feed the same number of batches, and a batch's keys must stay untouched until its
+        result has been yielded.  A yielded tensor lives in one of `backend.pipeline_depth` rotating
+        receive slots: at most pipeline_depth - 1 results may be held at a time (pulling result k recycles
+        the slot of result k - (pipeline_depth - 1); reads of it enqueued on the caller's stream before
+        that pull are safe).  A result is ready on the caller's current stream: no host sync is needed to
+        use it."""
+        be = self.backend
+        G = self.world
+        if G == 1 and not (force_exchange and dist.is_initialized()):
+            for keys in batches:
+                yield be.local_sort(keys)
+            return
+        depth = int(be.pipeline_depth)
+        sorted_ev = [None] * depth      # slot -> event: the local sort that last used the slot has finished
+        arrived = None                  # (recv tensor, event: its all-to-all has completed, slot)
+        for i, keys in enumerate(batches):
+            slot = i % depth
+            with be.exchange_scope(after_caller=True):
+                part, counts = be.partition_msb(keys, G, out=be.part_buffer(slot, keys.numel()))
+                matrix = torch.empty(G * G, dtype=counts.dtype, device=counts.device)
+                dist.all_gather_into_tensor(matrix, counts, group=self.group)
+            out = None
+            if arrived is not None:
+                # enqueue the previous batch's local sort BEFORE the host blocks on this batch's counts
+                out = self._sort_arrived(arrived, sorted_ev)
+            with be.exchange_scope():
+                send_splits, recv_splits = self._splits(matrix)
+                be.wait(sorted_ev[slot])        # the slot's previous occupant has been sorted (and handed out)
+                recv = be.recv_buffer(slot, sum(recv_splits))
+                dist.all_to_all_single(recv, part, recv_splits, send_splits, group=self.group)
+                arrived = (recv, be.event(), slot)
+            if out is not None:
+                yield out
+        if arrived is not None:
+            yield self._sort_arrived(arrived, sorted_ev)
+
+    def _sort_arrived(self, arrived, sorted_ev):
+        be = self.backend
+        recv, ev, slot = arrived
+        with be.sort_scope(after=ev):
+            be.local_sort(recv)
+            sorted_ev[slot] = be.event()
+        be.wait(sorted_ev[slot])        # outside the scopes = the caller's stream: the result is ready there
+        return recv

@@ -63,6 +63,15 @@ class Pprims:
         if self.m_work.getSize() < work_bytes:
             self.m_work.setSize(work_bytes)
 
+    def reserve(self, device, kind, n):
+        """Size the scratch for sorts of up to n elements of `kind` now, so that later calls do not grow it
+        (growing syncs the device and reallocates, uArray.h:124-132)."""
+        tb = ctypes.c_size_t()
+        wb = ctypes.c_size_t()
+        check(_lib.load().adlhip_radix_sort_scratch_bytes(device._h, kind, int(n), ctypes.byref(tb), ctypes.byref(wb)),
+              "adlhip_radix_sort_scratch_bytes")
+        self._scratch(device, (2 if kind == ELEM_SOA32 else 1) * tb.value, wb.value)
+
     def _sort(self, device, kind, fn, inout, n, sortBits):
         if device is None:
             raise AdlHipError("radixSort needs a device (the Python mirror has no host fallback)")

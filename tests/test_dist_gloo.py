@@ -2,6 +2,7 @@
 (oclradixsort_amd/dist.py: split arithmetic, all-gather of the count matrix, all_to_all_single with
 ragged splits, source-rank order of the received segments).  The device work is supplied by a numpy
 test backend defined HERE (tests only) -- the product package has no CPU backend."""
+import contextlib
 import os
 import socket
 import sys
@@ -16,21 +17,72 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 class NumpyBackend:
-    """Stands in for HipBackend: same three methods, on CPU tensors, using the oracle."""
+    """Stands in for HipBackend: same methods, on CPU tensors, using the oracle.  The pipeline plumbing
+    (streams, events) degenerates to bookkeeping that records the ORDER in which the host logic issued
+    the stages, so the test can check the software pipeline's schedule."""
+
+    pipeline_depth = 3
+
+    def __init__(self):
+        self.log = []
+        self._scope = "caller"
+        self._slots = {}
 
     def empty(self, n):
         return torch.empty(int(n), dtype=torch.int32)
 
-    def partition_msb(self, keys, num_buckets):
+    @contextlib.contextmanager
+    def exchange_scope(self, after_caller=False):
+        prev, self._scope = self._scope, "exchange"
+        try:
+            yield
+        finally:
+            self._scope = prev
+
+    @contextlib.contextmanager
+    def sort_scope(self, after=None):
+        assert after is not None
+        prev, self._scope = self._scope, "sort"
+        try:
+            yield
+        finally:
+            self._scope = prev
+
+    def event(self, timing=False):
+        return (self._scope, len(self.log))
+
+    def wait(self, ev):
+        pass
+
+    def _slot(self, kind, slot, n):
+        t = self._slots.get((kind, slot))
+        if t is None or t.numel() < n:
+            t = self._slots[(kind, slot)] = torch.empty(int(n) + 7, dtype=torch.int32)
+        return t[:n]
+
+    def recv_buffer(self, slot, n):
+        assert 0 <= slot < self.pipeline_depth
+        return self._slot("recv", slot, n)
+
+    def part_buffer(self, slot, n):
+        return self._slot("part", slot, n)
+
+    def partition_msb(self, keys, num_buckets, out=None):
+        self.log.append(("partition", self._scope))
         k = keys.numpy().view(np.uint32)
         lg = num_buckets.bit_length() - 1
         bucket = (k >> np.uint32(32 - lg)).astype(np.int64) if lg else np.zeros(k.size, dtype=np.int64)
         order = np.argsort(bucket, kind="stable")
         counts = np.bincount(bucket, minlength=num_buckets).astype(np.int32)
-        return torch.from_numpy(k[order].view(np.int32).copy()), torch.from_numpy(counts)
+        res = torch.from_numpy(k[order].view(np.int32).copy())
+        if out is not None:
+            out.copy_(res)
+            res = out
+        return res, torch.from_numpy(counts)
 
     def local_sort(self, keys):
         import oracle
+        self.log.append(("sort", self._scope))
         k = keys.numpy().view(np.uint32)
         k[:] = oracle.sort_u32(k)
         return keys
@@ -57,6 +109,38 @@ def _worker(rank, world, port, n_per_rank, skew, out_dir):
         dist.destroy_process_group()
 
 
+def _stream_worker(rank, world, port, sizes, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from oclradixsort_amd.dist import ShardedRadixSort
+        be = NumpyBackend()
+        sorter = ShardedRadixSort(be)
+        batches = []
+        for b, n in enumerate(sizes):
+            keys = oracle.keys_u32(n, seed=500 + b, first_index=rank * n)
+            if b % 2:   # every other batch skewed: ragged splits that change from batch to batch
+                keys = np.where(np.arange(n) % 7 != 0, keys >> np.uint32(2 + b % 3), keys).astype(np.uint32)
+            np.save(os.path.join(out_dir, "in_%d_%d.npy" % (b, rank)), keys)
+            batches.append(torch.from_numpy(keys.view(np.int32).copy()))
+        got = 0
+        for b, res in enumerate(sorter.sort_stream(batches)):
+            # a result must be intact when it is handed out AND stay intact while later batches are in flight
+            np.save(os.path.join(out_dir, "out_%d_%d.npy" % (b, rank)), res.numpy().view(np.uint32))
+            got += 1
+        assert got == len(sizes)
+        # schedule: batch i+1's partition is issued (exchange stage) before batch i's local sort (sort stage)
+        kinds = [k for k, _ in be.log]
+        assert all(scope == ("exchange" if k == "partition" else "sort") for k, scope in be.log)
+        want = ["partition"] + ["partition", "sort"] * (len(sizes) - 1) + ["sort"]
+        assert kinds == want, kinds
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -77,6 +161,32 @@ def test_sharded_sort_world2_gloo(tmp_path, skew):
     assert np.array_equal(got, want)
     for r, o in enumerate(outs):                     # bucket ownership: top bit == rank
         assert o.size == 0 or ((o >> np.uint32(31)) == r).all()
+
+
+def test_pipelined_sort_stream_world2_gloo(tmp_path):
+    """sort_stream: 6 batches of changing size and skew through the two-stage pipeline; every batch's
+    output equals the oracle's sort of that batch's global input, and the stages were issued in
+    software-pipeline order."""
+    import oracle
+    world = 2
+    sizes = [40009, 1000, 52345, 0, 33333, 47001]
+    mp.spawn(_stream_worker, args=(world, _free_port(), sizes, str(tmp_path)), nprocs=world, join=True)
+    for b in range(len(sizes)):
+        ins = [np.load(tmp_path / ("in_%d_%d.npy" % (b, r))) for r in range(world)]
+        outs = [np.load(tmp_path / ("out_%d_%d.npy" % (b, r))) for r in range(world)]
+        assert np.array_equal(np.concatenate(outs), oracle.sort_u32(np.concatenate(ins))), "batch %d" % b
+        for r, o in enumerate(outs):
+            assert o.size == 0 or ((o >> np.uint32(31)) == r).all()
+
+
+def test_sort_stream_without_process_group_is_a_plain_local_sort():
+    from oclradixsort_amd.dist import ShardedRadixSort
+    import oracle
+    s = ShardedRadixSort(NumpyBackend())
+    ks = [oracle.keys_u32(n, 9 + n) for n in (10, 0, 777)]
+    outs = list(s.sort_stream(torch.from_numpy(k.view(np.int32).copy()) for k in ks))
+    for k, o in zip(ks, outs):
+        assert np.array_equal(o.numpy().view(np.uint32), oracle.sort_u32(k))
 
 
 def test_world_size_must_be_power_of_two():

@@ -438,6 +438,59 @@ def test_msb_partition_and_simulated_exchange():
         be.close()
 
 
+def test_pipelined_sort_stream_over_rccl_one_rank():
+    """sort_stream on the GPU: partition + all-gather + all-to-all (RCCL, a one-rank group) on the exchange
+    stream overlapped with the previous batch's local sort on the sort stream.  Batches of changing size and
+    skew, results checked bit-exactly while the newest allowed number of later results is held too."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from oclradixsort_amd.dist import HipBackend, ShardedRadixSort
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    be = None
+    try:
+        be = HipBackend(0)
+        sorter = ShardedRadixSort(be)
+        sizes = [1 << 20, 300007, 5, 0, (1 << 22) + 13, 1 << 20, 999, 2000003, 1 << 21]
+        ins = []
+        for b, n in enumerate(sizes):
+            k = oracle.keys_u32(n, seed=900 + b)
+            if b % 3 == 1:
+                k = (k >> np.uint32(9)).astype(np.uint32)
+            ins.append(k)
+        dev_in = [torch.from_numpy(k.view(np.int32).copy()).cuda() for k in ins]
+        held = []     # (batch, tensor) not yet checked; at most pipeline_depth - 1 results may be held at a time
+        checked = 0
+        def check_one(b, t):
+            got = t.cpu().numpy().view(np.uint32)      # .cpu() runs on the caller's stream: must already be ordered
+            assert np.array_equal(got, oracle.sort_u32(ins[b])), "batch %d (n = %d)" % (b, sizes[b])
+        for b, res in enumerate(sorter.sort_stream(dev_in, force_exchange=True)):
+            assert res.numel() == sizes[b]
+            held.append((b, res))
+            if len(held) >= be.pipeline_depth - 1:
+                check_one(*held.pop(0))
+                checked += 1
+        for item in held:
+            check_one(*item)
+            checked += 1
+        assert checked == len(sizes)
+        # the serial driver gives the same answer through the same collectives
+        r = sorter.sort(dev_in[1].clone(), force_exchange=True)
+        assert np.array_equal(r.cpu().numpy().view(np.uint32), oracle.sort_u32(ins[1]))
+    finally:
+        if be is not None:
+            be.close()
+        dist.destroy_process_group()
+
+
 def test_generated_keys_match_the_oracle_generator(dev):
     n = 100001
     for kind, dtype, want in ((0, np.uint32, oracle.keys_u32(n, 123, 77)), (1, np.uint64, oracle.pairs_kv32(n, 123, 77)),
