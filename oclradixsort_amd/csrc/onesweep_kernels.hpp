@@ -39,8 +39,10 @@
 #include "radix_kernels.hpp"
 
 #ifndef ADLHIP_WRITE_UNROLL
-#define ADLHIP_WRITE_UNROLL 4
+#define ADLHIP_WRITE_UNROLL 8
 #endif
+// Diagnostic builds only (never the shipped library; results are WRONG, only the timing is of interest):
+// -DADLHIP_NO_LOOKBACK replaces the look-back by the analytic prefix of uniform keys (nothing polled or published)
 
 
 namespace adlhip {
@@ -408,31 +410,73 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTab
     uint32_t* my_wcnt = s_wcnt + w * BINS;
     const bool bk = (w == 0) && (lane < BK_LANES);
 
-    // ---- ticket: (chain, index in chain) -------------------------------------------------------
+#ifdef ADLHIP_STAMPS
+    // diagnostic: time and place of the workgroup's first instruction (stored once the tile id is known)
+    unsigned long long st_entry = 0ull, st_rt = 0ull;
+    uint32_t st_hw = 0u, st_xcc = 0u;
     if (tid == 0) {
-        uint32_t chain = 0xffffffffu, index = 0u;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_entry)::"memory");
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt)::"memory");
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(st_hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(st_xcc));
+    }
+#endif
+    // ---- ticket: (chain, index in chain) -------------------------------------------------------
+    // ONE global round trip before the tile's keys can be requested: wave 0 fetches the pass's 34 table words
+    // (lanes 0..16 tile_start, 17..33 chunk_start) and takes a ticket of its home chain (lane 34) in the same
+    // breath -- speculatively: a ticket beyond the chain's tile count is simply void.  (Done one after the other
+    // -- tile count, ticket, table words -- this preamble cost three dependent round trips per tile.)
+    if (w == 0) {
         const uint32_t c0 = blockIdx.x % (uint32_t)kChains;
-        for (int k = 0; k < kChains; ++k) {
-            const uint32_t c = (c0 + (uint32_t)k) % (uint32_t)kChains;
-            const uint32_t tiles_c = table->tile_start[c + 1] - table->tile_start[c];
-            if (tiles_c == 0u) continue;
-            const uint32_t i = atomicAdd(&tickets[c], 1u);
-            if (i < tiles_c) { chain = c; index = i; break; }
+        uint32_t v = 0u;
+        if (lane <= kChains) v = table->tile_start[lane];
+        else if (lane <= 2 * kChains + 1) v = table->chunk_start[lane - (kChains + 1)];
+        else if (lane == 2 * kChains + 2) v = atomicAdd(&tickets[c0], 1u);
+        auto at = [&](uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
+        uint32_t chain = c0;
+        uint32_t index = at(2 * kChains + 2);
+        if (index >= at(c0 + 1u) - at(c0)) {   // home chain exhausted (or empty): probe the others in turn
+            chain = 0xffffffffu;
+            for (int k = 1; k < kChains; ++k) {
+                const uint32_t c = (c0 + (uint32_t)k) % (uint32_t)kChains;
+                const uint32_t tiles_c = at(c + 1u) - at(c);
+                if (tiles_c == 0u) continue;
+                uint32_t i = 0u;
+                if (lane == 0) i = atomicAdd(&tickets[c], 1u);
+                i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+                if (i < tiles_c) { chain = c; index = i; break; }
+            }
         }
-        s_misc[0] = chain;
-        s_misc[1] = index;
+        if (lane == 0) {
+            s_misc[0] = chain;
+            s_misc[1] = index;
+            if (chain != 0xffffffffu) {
+                const uint32_t elem0 = at(kChains + 1u + chain) + index * (uint32_t)C::TILE;
+                s_misc[2] = at(chain);                              // first status row of the chain
+                s_misc[3] = elem0;
+                s_misc[4] = at(kChains + 2u + chain) - elem0;       // elements from the tile's start to the chain's end
+            }
+        }
     }
     __syncthreads();
     const uint32_t chain = s_misc[0];
     if (chain == 0xffffffffu) return;   // every chain is fully ticketed (the grid is an upper bound on the tile count)
     const uint32_t index = s_misc[1];
-    const uint32_t first_row = table->tile_start[chain];
+    const uint32_t first_row = s_misc[2];
     const uint32_t tile = first_row + index;                  // status row of this tile
-    const uint32_t elem0 = table->chunk_start[chain] + index * (uint32_t)C::TILE;
-    const uint32_t left = table->chunk_start[chain + 1] - elem0;
+    const uint32_t elem0 = s_misc[3];
+    const uint32_t left = s_misc[4];
     const uint32_t valid = left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE;
     ADLHIP_STAMP(tile, 0);
+#ifdef ADLHIP_STAMPS
+    if (tid == 0 && g_stamp_buf) {
+        g_stamp_buf[(size_t)tile * 16 + 11] = st_entry;
+        g_stamp_buf[(size_t)tile * 16 + 12] = (unsigned long long)st_hw | ((unsigned long long)st_xcc << 32);
+        g_stamp_buf[(size_t)tile * 16 + 13] = st_rt;
+    }
+#endif
 
+    const bool scaled = dst_fits32<IO>(n);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(status, 0, (int)status_bytes, 0x00020000);
     u32x4 gb = {0u, 0u, 0u, 0u};
     if (bk) gb = *reinterpret_cast<const u32x4*>(&table->cbase[chain][4 * lane]);
@@ -514,11 +558,13 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTab
         for (int j0 = 0; j0 < K; j0 += CH) {
             uint32_t pos[CH];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) pos[j] = my_wcnt[digit_of<NBITS>(e[j0 + j], start_bit)];
+            for (int j = 0; j < CH; ++j) pos[j] = my_wcnt[digit_of<NBITS>(e[(j0 + j < K) ? j0 + j : K - 1], start_bit)];
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
-                const uint32_t r = (rnk2[(j0 + j) >> 1] >> (16 * ((j0 + j) & 1))) & 0xffffu;
-                s_elems[pos[j] + r] = e[j0 + j];
+                if (j0 + j < K) {   // K need not be a multiple of CH
+                    const uint32_t r = (rnk2[(j0 + j) >> 1] >> (16 * ((j0 + j) & 1))) & 0xffffu;
+                    s_elems[pos[j] + r] = e[j0 + j];
+                }
             }
         }
     }
@@ -527,28 +573,32 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTab
     // ---- look-back (as late as possible) -------------------------------------------------------------
     if (bk) {
         u32x4 excl = {0u, 0u, 0u, 0u};
+#ifdef ADLHIP_NO_LOOKBACK
+        excl.x = excl.y = excl.z = excl.w = index * (uint32_t)(C::TILE / BINS);
+#else
         if (index != 0u) {
             excl = lookback_exclusive4<BINS, kLookbackWindow>(rsrc, tile, first_row, lane, fault, start_bit);
             __builtin_amdgcn_raw_buffer_store_b128(((excl + cnt4) & kValMask) | kFlagPfx, rsrc,
                                                    (tile * (uint32_t)BINS + 4u * (uint32_t)lane) * 4u, 0, 16);
         }
-        *reinterpret_cast<u32x4*>(s_goff + 4 * lane) = gb + excl - toff4;
+#endif
+        const u32x4 go = gb + excl - toff4;   // dst index = goff[d] + tile position (mod 2^32); bytes on the buffer-store path
+        *reinterpret_cast<u32x4*>(s_goff + 4 * lane) = scaled ? go * (uint32_t)IO::kStoreScale : go;
     }
     ADLHIP_STAMP(tile, 7);
     __syncthreads();   // C
     ADLHIP_STAMP(tile, 9);
 
     // ---- write-out ---------------------------------------------------------------------------------
-#pragma unroll ADLHIP_WRITE_UNROLL
-    for (int i = 0; i < K; ++i) {
-        if (i * NT < (int)valid - tid) {   // tile position tid + i*NT exists
-            const E v = s_elems[tid + i * NT];
-            const uint32_t d = digit_of<NBITS>(v, start_bit);
-            const uint32_t g = s_goff[d] + (uint32_t)(tid + i * NT);
-            if (g < n) io.store((size_t)g, v);   // always true for a sound offset (guards a faulted look-back)
-        }
-    }
+    write_out_tile<IO, NBITS, NT, K, ADLHIP_WRITE_UNROLL>(io, s_elems, s_goff, valid, n, start_bit, scaled);
     ADLHIP_STAMP(tile, 10);
+#ifdef ADLHIP_STAMPS
+    if (tid == 0 && g_stamp_buf) {
+        unsigned long long rt;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+        g_stamp_buf[(size_t)tile * 16 + 14] = rt;
+    }
+#endif
 }
 
 // counts[k] = number of keys whose top log2(num_buckets) bits equal k, from the 256 top-byte totals.

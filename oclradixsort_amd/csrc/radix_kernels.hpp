@@ -161,6 +161,26 @@ struct AosIO {
     };
     __device__ __forceinline__ Cursor cursor(size_t base) const { return Cursor{src + base}; }
     __device__ __forceinline__ void store(size_t i, E v) const { dst[i] = v; }
+    // Destination as a raw buffer: stores take a 32-bit BYTE offset and the hardware drops any store beyond
+    // n elements (no 64-bit address arithmetic, no compare + exec masking per element).
+    static constexpr uint32_t kStoreScale = (uint32_t)sizeof(E);   // bytes per element in a destination array
+    struct Dst {
+        __amdgpu_buffer_rsrc_t r;
+    };
+    __device__ __forceinline__ Dst make_dst(uint32_t n) const
+    {
+        return Dst{__builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(n * (uint32_t)sizeof(E)), 0x00020000)};
+    }
+    static __device__ __forceinline__ void store_at(const Dst& d, uint32_t byte_off, E v)
+    {
+        if constexpr (sizeof(E) == 4) {
+            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)v, d.r, (int)byte_off, 0, 0);
+        } else {
+            typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x2_t t = {(uint32_t)v, (uint32_t)((uint64_t)v >> 32)};
+            __builtin_amdgcn_raw_buffer_store_b64(t, d.r, (int)byte_off, 0, 0);
+        }
+    }
 };
 struct SoaIO {
     typedef uint64_t elem_t;
@@ -179,7 +199,78 @@ struct SoaIO {
         kdst[i] = (uint32_t)v;
         vdst[i] = (uint32_t)(v >> 32);
     }
+    static constexpr uint32_t kStoreScale = 4u;   // two arrays of 4-byte elements
+    struct Dst {
+        __amdgpu_buffer_rsrc_t k, v;
+    };
+    __device__ __forceinline__ Dst make_dst(uint32_t n) const
+    {
+        return Dst{__builtin_amdgcn_make_buffer_rsrc(kdst, 0, (int)(n * 4u), 0x00020000),
+                   __builtin_amdgcn_make_buffer_rsrc(vdst, 0, (int)(n * 4u), 0x00020000)};
+    }
+    static __device__ __forceinline__ void store_at(const Dst& d, uint32_t byte_off, uint64_t v)
+    {
+        __builtin_amdgcn_raw_buffer_store_b32((uint32_t)v, d.k, (int)byte_off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(v >> 32), d.v, (int)byte_off, 0, 0);
+    }
 };
+
+// Buffer stores need every element of a destination array within reach of a 32-bit byte offset; they are USED
+// for arrays up to 256 MiB, where they measured faster than pointer stores (64Mi u32 keys: +2.8 %, 32Mi: +3.5 %);
+// at 512 MiB the two are level and at 1 GiB pointer stores win by 1.3 % (profiles/r1_bufstore_ab.txt).
+template <typename IO>
+__device__ __forceinline__ bool dst_fits32(uint32_t n)
+{
+#ifdef ADLHIP_NO_BUFSTORE   // diagnostic builds: always take the pointer path
+    return false;
+#else
+    return (uint64_t)n * IO::kStoreScale <= (256ull << 20);
+#endif
+}
+
+// Write-out of a tile-sorted tile: consecutive threads -> consecutive tile positions -> contiguous runs per
+// digit (reference paper eq. 2: dst = run start + position - tile offset of the digit).  s_goff[d] holds
+// (run start - tile offset) of digit d, in BYTES of the destination array when `scaled` (the buffer-store
+// path: one v_add3 per element, bounds checked by the hardware), in elements otherwise (arrays of 4 GiB and more).
+template <typename IO, int NBITS, int NT, int K, int UNROLL>
+__device__ __forceinline__ void write_out_tile(const IO& io, const typename IO::elem_t* s_elems, const uint32_t* s_goff,
+                                               uint32_t valid, uint32_t n_total, int start_bit, bool scaled)
+{
+    typedef typename IO::elem_t E;
+    constexpr uint32_t SC = IO::kStoreScale;
+    const int tid = (int)threadIdx.x;
+    if (scaled) {
+        const typename IO::Dst dst = io.make_dst(n_total);
+        const uint32_t tsc = (uint32_t)tid * SC;
+        if (valid == (uint32_t)(NT * K)) {
+#pragma unroll UNROLL
+            for (int i = 0; i < K; ++i) {
+                const E v = s_elems[tid + i * NT];
+                const uint32_t d = digit_of<NBITS>(v, start_bit);
+                IO::store_at(dst, s_goff[d] + tsc + (uint32_t)(i * NT) * SC, v);
+            }
+        } else {
+#pragma unroll UNROLL
+            for (int i = 0; i < K; ++i) {
+                if (i * NT < (int)valid - tid) {   // tile position tid + i*NT exists
+                    const E v = s_elems[tid + i * NT];
+                    const uint32_t d = digit_of<NBITS>(v, start_bit);
+                    IO::store_at(dst, s_goff[d] + tsc + (uint32_t)(i * NT) * SC, v);
+                }
+            }
+        }
+    } else {
+#pragma unroll UNROLL
+        for (int i = 0; i < K; ++i) {
+            if (i * NT < (int)valid - tid) {
+                const E v = s_elems[tid + i * NT];
+                const uint32_t d = digit_of<NBITS>(v, start_bit);
+                const uint32_t g = s_goff[d] + (uint32_t)(tid + i * NT);
+                if (g < n_total) io.store((size_t)g, v);   // always true for a sound offset
+            }
+        }
+    }
+}
 
 // Stable rank of each of a lane's K elements among the wave's elements with the same digit, in
 // (item, lane) order; my_wcnt[digit] ends up holding the wave's count per digit (it must be zero on
@@ -197,10 +288,16 @@ __device__ __forceinline__ void rank_in_wave(const E (&e)[K], uint32_t (&rnk)[K]
         // sorts up to 3.5x slower).  One check per wave and tile: if all 64*K elements of this wave share a
         // digit, their ranks are simply item*64 + lane.  Costs ~1 VALU per element on random data and keeps the
         // K atomics below back to back.
-        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)digit_of<NBITS>(e[0], start_bit));
-        bool same = true;
+        const uint32_t dg0 = digit_of<NBITS>(e[0], start_bit);
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dg0);
+        // screen on ONE element per lane (one compare on random data, and the ranking below can start as soon as
+        // e[0] has landed instead of waiting for all K loads); the exact test runs only when the screen passes
+        bool same = false;
+        if (__all(dg0 == d0)) {
+            same = true;
 #pragma unroll
-        for (int j = 0; j < K; ++j) same &= digit_of<NBITS>(e[j], start_bit) == d0;
+            for (int j = 1; j < K; ++j) same &= digit_of<NBITS>(e[j], start_bit) == d0;
+        }
         if (__all(same)) {
 #pragma unroll
             for (int j = 0; j < K; ++j) rnk[j] = (uint32_t)(j * 64 + lane_id());
@@ -263,6 +360,7 @@ __device__ __forceinline__ void sort_scatter_tile(const IO& io, uint32_t tile_ba
     const int w = tid >> 6;
     uint32_t* my_wcnt = s_wcnt + w * BINS;
 
+    const bool scaled = dst_fits32<IO>(n_total);
     const uint32_t stamp_tile = tile_base / (uint32_t)C::TILE;
     (void)stamp_tile;
     ADLHIP_STAMP(stamp_tile, 0);
@@ -336,7 +434,8 @@ __device__ __forceinline__ void sort_scatter_tile(const IO& io, uint32_t tile_ba
         ADLHIP_STAMP(stamp_tile, 4);
         const uint32_t gstart = bin_offset(tid, cnt_b);
         ADLHIP_STAMP(stamp_tile, 5);
-        s_goff[tid] = gstart - toff;        // dst index = goff[d] + tile position (mod 2^32)
+        // dst index = goff[d] + tile position (mod 2^32); in bytes for the buffer-store path
+        s_goff[tid] = scaled ? (gstart - toff) * IO::kStoreScale : gstart - toff;
     }
     __syncthreads();
     ADLHIP_STAMP(stamp_tile, 6);
@@ -349,11 +448,13 @@ __device__ __forceinline__ void sort_scatter_tile(const IO& io, uint32_t tile_ba
         for (int j0 = 0; j0 < K; j0 += CH) {
             uint32_t pos[CH];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) pos[j] = my_wcnt[digit_of<NBITS>(e[j0 + j], start_bit)];
+            for (int j = 0; j < CH; ++j) pos[j] = my_wcnt[digit_of<NBITS>(e[(j0 + j < K) ? j0 + j : K - 1], start_bit)];
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
-                const uint32_t r = (rnk2[(j0 + j) >> 1] >> (16 * ((j0 + j) & 1))) & 0xffffu;
-                s_elems[pos[j] + r] = e[j0 + j];
+                if (j0 + j < K) {   // K need not be a multiple of CH
+                    const uint32_t r = (rnk2[(j0 + j) >> 1] >> (16 * ((j0 + j) & 1))) & 0xffffu;
+                    s_elems[pos[j] + r] = e[j0 + j];
+                }
             }
         }
     }
@@ -361,16 +462,7 @@ __device__ __forceinline__ void sort_scatter_tile(const IO& io, uint32_t tile_ba
     __syncthreads();
     ADLHIP_STAMP(stamp_tile, 8);
 
-    // write-out: consecutive threads -> consecutive tile positions -> contiguous runs per digit
-#pragma unroll 4
-    for (int i = 0; i < K; ++i) {
-        if (i * NT < (int)valid - tid) {   // tile position tid + i*NT exists
-            const E v = s_elems[tid + i * NT];
-            const uint32_t d = digit_of<NBITS>(v, start_bit);
-            const uint32_t g = s_goff[d] + (uint32_t)(tid + i * NT);
-            if (g < n_total) io.store((size_t)g, v);   // always true for a sound offset
-        }
-    }
+    write_out_tile<IO, NBITS, NT, K, 4>(io, s_elems, s_goff, valid, n_total, start_bit, scaled);
     ADLHIP_STAMP(stamp_tile, 9);
     __syncthreads();   // LDS is reused by the next tile
     ADLHIP_STAMP(stamp_tile, 10);
