@@ -43,12 +43,13 @@ int main(int argc, char** argv)
     uint32_t *a, *b;
     HK(hipMalloc(&a, n * 4 + 256)); HK(hipMalloc(&b, n * 4 + 256));
     HK(hipMemset(a, 1, n * 4)); HK(hipMemset(b, 2, n * 4));
-    const size_t lds = 73 * 1024;
+    const size_t lds = (argc > 2 ? strtoull(argv[2], 0, 0) : 73) * 1024;   // KiB of LDS per workgroup = workgroups per CU
     HK(hipFuncSetAttribute((const void*)scatter_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; HK(hipEventCreate(&e0)); HK(hipEventCreate(&e1));
+    printf("LDS per workgroup %zu KiB -> %d workgroup(s) of %d threads per CU\n", lds >> 10, (int)(160 * 1024 / lds), NT);
     printf("n = %zu keys, %u tiles of %d, ping-pong between two %zu-MiB buffers (like consecutive passes)\n", n, tiles, TILE, n * 4 >> 20);
     for (uint32_t mis : {0u, 1u})
-    for (uint32_t rl : {14u, 10u, 8u, 7u, 6u, 5u, 4u, 3u}) {
+    for (uint32_t rl : {14u, 8u, 6u, 5u, 4u}) {
         for (int k = 0; k < 3; ++k) { scatter_probe<<<tiles, NT, lds>>>(a, b, rl, tpc, mis); scatter_probe<<<tiles, NT, lds>>>(b, a, rl, tpc, mis); }
         HK(hipEventRecord(e0));
         const int reps = 10;
