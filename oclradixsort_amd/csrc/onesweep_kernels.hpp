@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void onesweep_tables_kernel(const uint32_t* __
                                                               uint32_t tile)
 {
     __shared__ uint32_t wsum[256 / 64 + 1];
-    __shared__ uint32_t rowtot[kChains];
+    __shared__ uint32_t rowpart[256 / 64][kChains];   // per wave: partial chain lengths
     const int p = (int)blockIdx.x;
     const int tid = (int)threadIdx.x;
     const int nb = desc.nbits[p];
@@ -293,31 +293,29 @@ __global__ __launch_bounds__(256) void onesweep_tables_kernel(const uint32_t* __
         col[c] = ((uint32_t)tid < bins) ? J[p == 0 ? (uint32_t)c * bins + (uint32_t)tid : (uint32_t)tid * (uint32_t)kChains + (uint32_t)c] : 0u;
         tot += col[c];
     }
-    const uint32_t gb = block_excl_scan_u32<256>(tot, wsum, nullptr);
+    // chain lengths = row sums: one DPP wave scan per chain, the four wave totals are added by the thread that needs them
+    // (sixteen block-wide scans = 32 barriers before)
+#pragma unroll
+    for (int c = 0; c < kChains; ++c) {
+        const uint32_t r = wave_incl_scan_u32(col[c]);
+        if ((tid & 63) == 63) rowpart[tid >> 6][c] = r;
+    }
+    const uint32_t gb = block_excl_scan_u32<256>(tot, wsum, nullptr);   // two barriers: rowpart is visible after them
     uint32_t run = gb;
 #pragma unroll
     for (int c = 0; c < kChains; ++c) {
         if ((uint32_t)tid < bins) T->cbase[c][tid] = run;
         run += col[c];
     }
-#pragma unroll
-    for (int c = 0; c < kChains; ++c) {   // chain lengths = row sums
-        uint32_t t2;
-        block_excl_scan_u32<256>(col[c], wsum, &t2);
-        if (tid == 0) rowtot[c] = t2;
-    }
-    __syncthreads();
-    if (tid == 0) {
+    if (tid <= kChains) {   // thread c: where chain c starts (elements and tiles); thread kChains: the totals
         uint32_t es = 0u, ts = 0u;
-        for (int c = 0; c < kChains; ++c) {
-            T->chunk_start[c] = es;
-            T->tile_start[c] = ts;
-            const uint32_t len = rowtot[c];
+        for (int c = 0; c < tid; ++c) {
+            const uint32_t len = rowpart[0][c] + rowpart[1][c] + rowpart[2][c] + rowpart[3][c];
             es += len;
             ts += (len + tile - 1u) / tile;
         }
-        T->chunk_start[kChains] = es;   // == n
-        T->tile_start[kChains] = ts;
+        T->chunk_start[tid] = es;   // [kChains] == n
+        T->tile_start[tid] = ts;
     }
 }
 
