@@ -630,8 +630,8 @@ struct SmallPlan {
     uint8_t nbits[16];
 };
 
-template <typename E, int NT, int K, int RANK>
-__global__ __launch_bounds__(NT) void small_sort_kernel(E* __restrict__ data, uint32_t n, SmallPlan plan)
+template <typename E, int NT, int K, int RANK, bool FULL>
+__device__ __forceinline__ void small_sort_body(E* __restrict__ data, uint32_t n, const SmallPlan& plan)
 {
     constexpr int BINS = 256;
     constexpr int NW = NT / 64;
@@ -645,14 +645,20 @@ __global__ __launch_bounds__(NT) void small_sort_kernel(E* __restrict__ data, ui
     const int lane = tid & 63;
     const int w = tid >> 6;
     uint32_t* my_wcnt = s_wcnt + w * BINS;
-    const uint32_t wbase = (uint32_t)(w * 64 * K + lane);
+    // Only ceil(n / NT) of the K items per thread are used, so that n < NT*K elements are spread over ALL waves
+    // (wave w owns elements [w*64*keff, (w+1)*64*keff)) and nothing is spent on empty slots: with the full K items
+    // 1 Ki keys sat in one wave, and thousands of all-ones pads queued up on one LDS counter in every pass
+    // (1 Ki keys took 18 us, 4 Ki + 1 keys 54 us; a full 16 Ki tile 19 us).
+    const int keff = FULL ? K : (int)((n + (uint32_t)NT - 1u) / (uint32_t)NT);   // 1..K (FULL: a compile-time K, no per-item branches)
+    const uint32_t wbase = (uint32_t)(w * 64 * keff + lane);
 
-    // wave-striped load; slots beyond n are padded with all-ones (they rank last and are never stored)
+    // wave-striped load; the < NT slots between n and keff*NT are padded with all-ones (they rank last, are never stored)
     E e[K];
     {
         const int rem = (int)n - (int)wbase;
 #pragma unroll
-        for (int j = 0; j < K; ++j) e[j] = (j * 64 < rem) ? data[wbase + (uint32_t)(j * 64)] : ~E(0);
+        for (int j = 0; j < K; ++j)
+            if (FULL || j < keff) e[j] = (j * 64 < rem) ? data[wbase + (uint32_t)(j * 64)] : ~E(0);
     }
 
     for (int p = 0; p < plan.num_passes; ++p) {
@@ -669,18 +675,21 @@ __global__ __launch_bounds__(NT) void small_sort_kernel(E* __restrict__ data, ui
         uint32_t rnk[K];
         if constexpr (RANK == 1) {
 #pragma unroll
-            for (int j = 0; j < K; ++j)   // (n <= 16 Ki: the same-digit serialisation does not matter here)
-                rnk[j] = __hip_atomic_fetch_add(&my_wcnt[digit(e[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int j = 0; j < K; ++j)
+                if (FULL || j < keff)
+                    rnk[j] = __hip_atomic_fetch_add(&my_wcnt[digit(e[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                const uint32_t d = digit(e[j]);
-                const uint64_t m = match_digit<8>(d);
-                const uint32_t below = mbcnt64(m);
-                const uint32_t old = __hip_atomic_load(&my_wcnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                if (below == 0u)
-                    __hip_atomic_fetch_add(&my_wcnt[d], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                rnk[j] = old + below;
+                if (FULL || j < keff) {   // wave-uniform: all 64 lanes take part in the ballots
+                    const uint32_t d = digit(e[j]);
+                    const uint64_t m = match_digit<8>(d);
+                    const uint32_t below = mbcnt64(m);
+                    const uint32_t old = __hip_atomic_load(&my_wcnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    if (below == 0u)
+                        __hip_atomic_fetch_add(&my_wcnt[d], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    rnk[j] = old + below;
+                }
             }
         }
         __syncthreads();
@@ -705,19 +714,28 @@ __global__ __launch_bounds__(NT) void small_sort_kernel(E* __restrict__ data, ui
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < K; ++j) s_elems[my_wcnt[digit(e[j])] + rnk[j]] = e[j];
+        for (int j = 0; j < K; ++j)
+            if (FULL || j < keff) s_elems[my_wcnt[digit(e[j])] + rnk[j]] = e[j];
         __syncthreads();
         // back to registers in wave-striped order = the order the next pass must preserve
 #pragma unroll
-        for (int j = 0; j < K; ++j) e[j] = s_elems[wbase + (uint32_t)(j * 64)];
+        for (int j = 0; j < K; ++j)
+            if (FULL || j < keff) e[j] = s_elems[wbase + (uint32_t)(j * 64)];
         __syncthreads();
     }
     {
         const int rem = (int)n - (int)wbase;
 #pragma unroll
         for (int j = 0; j < K; ++j)
-            if (j * 64 < rem) data[wbase + (uint32_t)(j * 64)] = e[j];
+            if ((FULL || j < keff) && j * 64 < rem) data[wbase + (uint32_t)(j * 64)] = e[j];
     }
+}
+
+template <typename E, int NT, int K, int RANK>
+__global__ __launch_bounds__(NT) void small_sort_kernel(E* __restrict__ data, uint32_t n, SmallPlan plan)
+{
+    if (n + (uint32_t)NT > (uint32_t)(NT * K)) small_sort_body<E, NT, K, RANK, true>(data, n, plan);   // all K items in use
+    else small_sort_body<E, NT, K, RANK, false>(data, n, plan);
 }
 
 // ------------------------------------------------------------------------------------------

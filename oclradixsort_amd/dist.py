@@ -98,7 +98,10 @@ class HipBackend:
     def _stage(self, which):
         st = getattr(self, which)
         if st is None:
-            st = _Stage(self.local_rank, torch.cuda.Stream(device=self.torch_device))
+            # the exchange stage feeds the xGMI links, the scarcer resource: its (short) partition kernels go first so that
+            # the next all-to-all starts as early as possible under the running local sort
+            prio = -1 if which == "_exchange" else 0
+            st = _Stage(self.local_rank, torch.cuda.Stream(device=self.torch_device, priority=prio))
             for k, v in self._params.items():
                 st.device.setParam(k, v)
             setattr(self, which, st)

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of the dominant pass kernel from two rocprofv3 --pmc runs of bench.py (FETCH_SIZE, WRITE_SIZE;
+separate passes, --kernel-trace only): writes the JSON that bench.py reports as roofline.traffic.
+   python tools/pmc_traffic.py <dir with pmc_FETCH_SIZE/ and pmc_WRITE_SIZE/> <out.json> [keys_per_launch]
+gfx950 correction (MI355X_MICROARCH.md, HBM section; calibrated here against a known 256-MiB streaming read):
+FETCH_SIZE counts half the bytes of a coalesced streaming read -> x2; both counters are in KiB."""
+import csv, glob, json, os, sys
+root, out = sys.argv[1], sys.argv[2]
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 26
+vals = {}
+kname = None
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    tot, cnt = 0.0, 0
+    for f in glob.glob(os.path.join(root, "pmc_" + ctr, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                k = row.get("Kernel_Name", "")
+                if "onesweep_chain_kernel" in k and "unsigned int>, 8" in k and row.get("Counter_Name") == ctr:
+                    tot += float(row["Counter_Value"]); cnt += 1
+                    kname = k.split("(")[0].replace("void adlhip::", "")
+    if cnt == 0:
+        sys.exit("no %s rows for the pass kernel under %s" % (ctr, root))
+    vals[ctr] = (tot / cnt, cnt)
+fetch_kb, nf = vals["FETCH_SIZE"]; write_kb, nw = vals["WRITE_SIZE"]
+traffic = int(fetch_kb * 1024 * 2.0 + write_kb * 1024)
+json.dump({
+    "kernel": kname, "profile_name": "onesweep_u32_8b", "keys_per_launch": n, "launches_averaged": min(nf, nw),
+    "FETCH_SIZE_kb": round(fetch_kb, 1), "WRITE_SIZE_kb": round(write_kb, 1), "fetch_correction": 2.0,
+    "correction_note": "gfx950: FETCH_SIZE reports half of the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM); "
+                       "2 x FETCH_SIZE vs %.1f MB of keys + status rows" % (n * 4 / 1e6),
+    "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": 2 * n * 4,
+    "how": "two separate runs of `rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py --steps 5 --warmup 1 "
+           "--no-cpu-baseline --no-verify` (tools/gpu_session.sh)",
+}, open(out, "w"), indent=1)
+print(open(out).read())
