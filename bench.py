@@ -272,6 +272,8 @@ def main():
             "Gkeys_per_s": float(n) * world * K / serial_wall / 1e9,
             "rank0_stage_ms": {"partition": st[0] / K, "count_allgather_and_host_sync": st[1] / K,
                                "all_to_all": st[2] / K, "local_sort": st[3] / K},
+            # bytes this rank put on the links per step (everything but its own bucket) / the all-to-all's duration
+            "rank0_all_to_all_out_GBps": (sum(sorter.last_splits[0]) - sorter.last_splits[0][rank]) * 4.0 / max(st[2] / K * 1e-3, 1e-12) / 1e9,
             "note": "un-pipelined driver (ShardedRadixSort.sort), timed after the metric's region",
         }
         verified = None
