@@ -598,10 +598,27 @@ __global__ __launch_bounds__(NT) void radix_scatter_kernel(IO io, const uint32_t
     const int tid = (int)threadIdx.x;
     const uint32_t wg = blockIdx.x;
 
-    // digit bases = exclusive scan of the digit totals; carry = base + scanned table entry
-    const uint32_t tot_b = tid < C::BINS ? totals[tid] : 0u;
+    // digit bases = exclusive scan of the digit totals; carry = base + scanned table entry.
+    // totals == nullptr (few workgroups, launch-bound sizes): `table` holds the RAW counts and thread b scans its own
+    // row here -- n_wgs contiguous words -- which saves the table-scan launch and its kernel boundary (~2 us per pass at 16 workgroups;
+    // level at 32, a loss beyond: the row walk is a chain of memory latencies, the separate scan kernel one parallel sweep).
+    uint32_t tot_b = 0u, pre_b = 0u;
+    if (tid < C::BINS) {
+        if (totals) {
+            tot_b = totals[tid];
+            pre_b = table[(size_t)tid * n_wgs + wg];
+        } else {
+            const uint32_t* row = table + (size_t)tid * n_wgs;
+#pragma unroll 16
+            for (int j = 0; j < n_wgs; ++j) {   // n_wgs <= 16 here: one batch of independent loads
+                const uint32_t v = row[j];
+                tot_b += v;
+                pre_b += (j < (int)wg) ? v : 0u;
+            }
+        }
+    }
     const uint32_t base_b = block_excl_scan_u32<NT>(tot_b, s_wsum, nullptr);
-    uint32_t carry = tid < C::BINS ? base_b + table[(size_t)tid * n_wgs + wg] : 0u;
+    uint32_t carry = base_b + pre_b;
 
     const uint32_t t0 = wg * tiles_per_wg;
     const uint32_t t1 = (t0 + tiles_per_wg < num_tiles) ? t0 + tiles_per_wg : num_tiles;

@@ -1,9 +1,12 @@
+#!/usr/bin/env python3
+"""Small and launch-bound sizes: us per sort (200 back-to-back sorts) and which kernels ran."""
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oclradixsort_amd import Buffer, DeviceUtils, Pprims, Stopwatch
 d = DeviceUtils.allocate(); p = Pprims()
-for n in (1024, 2048, 3000, 4096, 4097, 6000, 8192, 12000, 16384, 16385):
+sizes = [int(x) for x in sys.argv[1:]] or [1024, 4096, 8192, 16384, 16385, 32768, 65536, 131072, 262144, 524288, 524289, 1048576, 2097152]
+for n in sizes:
     bufs = [Buffer(d, n, np.uint32) for _ in range(8)]
     for b in bufs: b.generate(n, seed=n)
     DeviceUtils.waitForCompletion(d)
@@ -15,5 +18,5 @@ for n in (1024, 2048, 3000, 4096, 4097, 6000, 8192, 12000, 16384, 16385):
     d.toggleProfiling(True); d.profile(reset=True)
     p.radixSort(d, bufs[0], n)
     prof = d.profile(reset=True); d.toggleProfiling(False)
-    print(n, "%.1f us" % (best * 1e3), {k: round(v[1] * 1e3, 1) for k, v in prof.items()})
+    print("%9d %7.1f us  %s" % (n, best * 1e3, {k: v[0] for k, v in prof.items()}))
     for b in bufs: b.release()
