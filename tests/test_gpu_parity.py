@@ -219,7 +219,7 @@ def test_small_demo_golden_vectors(dev, pp, golden_dir, algo):
 # ---------------------------------------------------------------------------------------------
 # edge cases the reference never tests
 # ---------------------------------------------------------------------------------------------
-RAGGED = [0, 1, 2, 63, 64, 65, 255, 256, 257, 1023, 4095, 4096, 4097, 8191, 8193, 12289, 65537, 262143, 1000003]
+RAGGED = [0, 1, 2, 63, 64, 65, 255, 256, 257, 1023, 4095, 4096, 4097, 8191, 8193, 12289, 16385, 50001, 65537, 262143, 1000003]
 
 
 @pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS)
@@ -255,6 +255,30 @@ def test_low_entropy_and_stability(dev, pp, algo):
         assert np.array_equal(gpu_sort_u32(dev, pp, k32), oracle.sort_u32(k32)), nm
         pairs = keys | (np.arange(n, dtype=np.uint64) << 32)    # value = original index
         assert np.array_equal(gpu_sort_kv(dev, pp, pairs), oracle.sort_kv32(pairs)), nm
+
+
+def test_low_entropy_at_one_workgroup_and_launch_bound_sizes(dev, pp):
+    """The one-workgroup sort (n <= 16 Ki: partly filled tile, all-ones pads behind the data) and the 8-launch
+    three-kernel path (n <= 64 Ki) on keys that collide with the pads or with each other."""
+    rng = np.random.RandomState(11)
+    for n in (1, 100, 1000, 4097, 5000, 16384, 20000, 65536):
+        cases = {
+            "all_max": np.full(n, 0xffffffff, dtype=np.uint64),          # equal to the pad pattern
+            "all_equal": np.full(n, 0x80000001, dtype=np.uint64),
+            "two_values": rng.randint(0, 2, n).astype(np.uint64) * 0xffffffff,
+            "top_byte_only": rng.randint(0, 256, n).astype(np.uint64) << 24,
+            "sorted": np.sort(rng.randint(0, 2**32, n, dtype=np.uint64)),
+        }
+        for nm, keys in cases.items():
+            k32 = keys.astype(np.uint32)
+            assert np.array_equal(gpu_sort_u32(dev, pp, k32), oracle.sort_u32(k32)), (nm, n)
+            pairs = keys | (np.arange(n, dtype=np.uint64) << 32)    # value = original index: stability is visible
+            assert np.array_equal(gpu_sort_kv(dev, pp, pairs), oracle.sort_kv32(pairs)), (nm, n)
+            k64 = keys | (keys << np.uint64(32))
+            assert np.array_equal(gpu_sort_u64(dev, pp, k64), oracle.sort_u64(k64)), (nm, n)
+        for bits in (4, 12, 20):   # partial sortBits through the same paths
+            k = oracle.keys_u32(n, seed=n + bits)
+            assert np.array_equal(gpu_sort_u32(dev, pp, k, bits), oracle.sort_u32_bits(k, bits)), (bits, n)
 
 
 @pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS)
