@@ -171,6 +171,11 @@ int adlhip_exclusive_scan_u32(adlhip_device* dev, uint32_t* d_dst, const uint32_
 int adlhip_partition_msb_u32(adlhip_device* dev, const uint32_t* d_keys_in, uint32_t* d_keys_out,
                              uint32_t* d_counts_out, void* d_work, size_t work_bytes,
                              size_t n, int num_buckets);
+/* Same for n {u32 key, u32 value} pairs (the element of Pprims::radixSort(Buffer<uint2>), Pprims.h:38): partitioned by
+ * the top bits of the KEY, stable, values travel with their keys. */
+int adlhip_partition_msb_kv32(adlhip_device* dev, const void* d_pairs_in, void* d_pairs_out,
+                              uint32_t* d_counts_out, void* d_work, size_t work_bytes,
+                              size_t n, int num_buckets);
 
 /* ---- synthetic inputs: generated in place, reproducible by index ---------- */
 

@@ -63,6 +63,7 @@ SIGNATURES = {
     "adlhip_scan_scratch_bytes": (_I, [_VP, _SZ, c_size_p]),
     "adlhip_exclusive_scan_u32": (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _VP]),
     "adlhip_partition_msb_u32": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
+    "adlhip_partition_msb_kv32": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
     "adlhip_generate_keys": (_I, [_VP, _I, _VP, _SZ, ctypes.c_uint64, ctypes.c_uint64]),
     "adlhip_set_param": (_I, [_VP, ctypes.c_char_p, _I]),
     "adlhip_get_param": (_I, [_VP, ctypes.c_char_p, ctypes.POINTER(_I)]),

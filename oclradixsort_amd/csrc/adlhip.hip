@@ -641,6 +641,47 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
     return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, n, plan);
 }
 
+// ---- MSB partition (multi-GPU send side) -----------------------------------------------------------
+// E = uint32_t (keys) or uint64_t ({key, value} pairs: the key is the low dword, so its top byte is bits 24..31)
+template <typename E>
+int partition_msb(adlhip_device* d, const E* in, E* out, uint32_t* counts, void* work, size_t work_bytes, size_t n,
+                         int num_buckets)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    int lg = 0;
+    while ((1 << lg) < num_buckets) ++lg;
+    if (num_buckets < 1 || num_buckets > 256 || (1 << lg) != num_buckets)
+        return fail("num_buckets must be a power of two in [1,256], got %d", num_buckets);
+    if (!counts) return fail("null counts pointer");
+    if (n > kMaxElems) return fail("n too large");
+    if (n == 0 || num_buckets == 1) {
+        HIPCHK(hipMemsetAsync(counts, 0, 4 * (size_t)num_buckets, d->stream));
+        if (n) {
+            if (!in || !out) return fail("null buffer");
+            HIPCHK(hipMemcpyAsync(out, in, n * sizeof(E), hipMemcpyDeviceToDevice, d->stream));
+            uint32_t nn = (uint32_t)n;
+            // counts[0] = n  (stream-ordered fill of one word)
+            int rc = launch(d, "fill_u32", [&] {
+                hipLaunchKernelGGL(adlhip::fill_u32_kernel, dim3(1), dim3(256), 0, d->stream, counts, nn, (size_t)1);
+            });
+            if (rc) return rc;
+        }
+        return ADLHIP_SUCCESS;
+    }
+    if (!in || !out) return fail("null buffer");
+    const size_t need = work_bytes_three_kernel(d, n);
+    if (work_bytes < need || !work) return fail("work buffer too small: %zu < %zu", work_bytes, need);
+    if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) return fail("buffers must be 16-byte aligned");
+    // one three-kernel pass on the top byte (the top `lg` bits decide the bucket; ordering by the
+    // whole top byte refines buckets without mixing them), then fold the 256 digit totals into buckets
+    int rc = three_kernel_pass<AosBuf<E>, 8>(d, AosBuf<E>{const_cast<E*>(in)}, AosBuf<E>{out}, work, n, 24, /*need_totals=*/true);
+    if (rc) return rc;
+    uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + table_bytes(d, n, kMinTile));
+    return launch(d, "fold_buckets", [&] {
+        hipLaunchKernelGGL(adlhip::fold_buckets_kernel, dim3(1), dim3(256), 0, d->stream, (const uint32_t*)totals, counts, num_buckets);
+    });
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -1018,38 +1059,14 @@ int adlhip_exclusive_scan_u32(adlhip_device* d, uint32_t* dst, const uint32_t* s
 int adlhip_partition_msb_u32(adlhip_device* d, const uint32_t* in, uint32_t* out, uint32_t* counts, void* work,
                              size_t work_bytes, size_t n, int num_buckets)
 {
-    if (bind(d)) return ADLHIP_FAILURE;
-    int lg = 0;
-    while ((1 << lg) < num_buckets) ++lg;
-    if (num_buckets < 1 || num_buckets > 256 || (1 << lg) != num_buckets)
-        return fail("num_buckets must be a power of two in [1,256], got %d", num_buckets);
-    if (!counts) return fail("null counts pointer");
-    if (n > kMaxElems) return fail("n too large");
-    if (n == 0 || num_buckets == 1) {
-        HIPCHK(hipMemsetAsync(counts, 0, 4 * (size_t)num_buckets, d->stream));
-        if (n) {
-            HIPCHK(hipMemcpyAsync(out, in, n * 4, hipMemcpyDeviceToDevice, d->stream));
-            uint32_t nn = (uint32_t)n;
-            // counts[0] = n  (stream-ordered fill of one word)
-            int rc = launch(d, "fill_u32", [&] {
-                hipLaunchKernelGGL(adlhip::fill_u32_kernel, dim3(1), dim3(256), 0, d->stream, counts, nn, (size_t)1);
-            });
-            if (rc) return rc;
-        }
-        return ADLHIP_SUCCESS;
-    }
-    const size_t need = work_bytes_three_kernel(d, n);
-    if (work_bytes < need || !work) return fail("work buffer too small: %zu < %zu", work_bytes, need);
-    if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) return fail("buffers must be 16-byte aligned");
-    // one three-kernel pass on the top byte (the top `lg` bits decide the bucket; ordering by the
-    // whole top byte refines buckets without mixing them), then fold the 256 digit totals into buckets
-    int rc = three_kernel_pass<AosBuf<uint32_t>, 8>(d, AosBuf<uint32_t>{const_cast<uint32_t*>(in)}, AosBuf<uint32_t>{out}, work, n, 24,
-                                                     /*need_totals=*/true);
-    if (rc) return rc;
-    uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + table_bytes(d, n, kMinTile));
-    return launch(d, "fold_buckets", [&] {
-        hipLaunchKernelGGL(adlhip::fold_buckets_kernel, dim3(1), dim3(256), 0, d->stream, (const uint32_t*)totals, counts, num_buckets);
-    });
+    return partition_msb<uint32_t>(d, in, out, counts, work, work_bytes, n, num_buckets);
+}
+
+int adlhip_partition_msb_kv32(adlhip_device* d, const void* in, void* out, uint32_t* counts, void* work, size_t work_bytes,
+                              size_t n, int num_buckets)
+{
+    return partition_msb<uint64_t>(d, static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), counts, work, work_bytes, n,
+                                   num_buckets);
 }
 
 // ---- synthetic inputs ---------------------------------------------------------------------------

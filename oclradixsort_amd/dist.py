@@ -34,7 +34,7 @@ import torch.distributed as dist
 from . import _lib
 from ._lib import check
 from .adl import Buffer, Config, DeviceUtils
-from .pprims import ELEM_U32, Pprims
+from .pprims import ELEM_KV32, ELEM_U32, Pprims
 
 
 class _Stage:
@@ -47,7 +47,7 @@ class _Stage:
         self.device = DeviceUtils.allocate(cfg=Config(local_rank), stream=raw)
         self.pprims = Pprims()
         self.work = None                # partition scratch
-        self.reserved = 0               # keys the sort scratch has been sized for
+        self.reserved = 0               # bytes of elements the sort scratch has been sized for
 
     def close(self):
         self.pprims.close()
@@ -155,7 +155,8 @@ class HipBackend:
         if ev is not None:
             torch.cuda.current_stream(self.torch_device).wait_event(ev)
 
-    def _slot_buffer(self, pool, slot, n):
+    def _slot_buffer(self, pool, slot, n, dtype=torch.int32):
+        slot = (slot, dtype)
         t = pool.get(slot)
         if t is None or t.numel() < n:
             # grow with headroom so that batch-to-batch jitter of the received count does not reallocate;
@@ -165,66 +166,76 @@ class HipBackend:
                     if st is not None:
                         t.record_stream(st.stream)
             cap = int(n) + int(n) // 16 + 1024
-            t = torch.empty(cap, dtype=torch.int32, device=self.torch_device)
+            t = torch.empty(cap, dtype=dtype, device=self.torch_device)
             pool[slot] = t
         return t[:n]
 
-    def recv_buffer(self, slot, n):
-        """Persistent receive buffer of pipeline slot `slot`, at least n keys (view of exactly n)."""
-        return self._slot_buffer(self._recv, slot, n)
+    def recv_buffer(self, slot, n, dtype=torch.int32):
+        """Persistent receive buffer of pipeline slot `slot`, at least n elements (view of exactly n)."""
+        return self._slot_buffer(self._recv, slot, n, dtype)
 
-    def part_buffer(self, slot, n):
-        return self._slot_buffer(self._part, slot, n)
+    def part_buffer(self, slot, n, dtype=torch.int32):
+        return self._slot_buffer(self._part, slot, n, dtype)
 
     # ---- device work -----------------------------------------------------------------------------
-    def empty(self, n):
-        return torch.empty(int(n), dtype=torch.int32, device=self.torch_device)
+    # element kinds: int32 tensors hold u32 keys, int64 tensors hold {u32 key (low dword), u32 value} pairs
+    def empty(self, n, dtype=torch.int32):
+        return torch.empty(int(n), dtype=dtype, device=self.torch_device)
 
     def _wrap(self, device, t):
-        b = Buffer(dtype=np.uint32)
+        b = Buffer(dtype=np.uint32 if t.dtype == torch.int32 else np.uint64)
         b.setRawPtr(device, t.data_ptr(), t.numel())
         return b
 
     def partition_msb(self, keys, num_buckets, out=None):
-        """keys: int32 CUDA tensor holding u32 bit patterns.  Returns (partitioned tensor, int32 CUDA
-        tensor of num_buckets segment sizes).  Runs on the stage of the scope we are in."""
+        """keys: int32 CUDA tensor holding u32 bit patterns, or int64 CUDA tensor holding {key, value} pairs.
+        Returns (partitioned tensor, int32 CUDA tensor of num_buckets segment sizes).  Runs on the stage of the
+        scope we are in."""
         ct = self._ct
         st = self._cur
         n = keys.numel()
+        if keys.dtype not in (torch.int32, torch.int64):
+            raise TypeError("sharded sort takes int32 (u32 keys) or int64 ({key, value} pairs) tensors, got %s" % keys.dtype)
+        pairs = keys.dtype == torch.int64
         if out is None:
-            out = self.empty(n)
+            out = self.empty(n, keys.dtype)
         counts = torch.zeros(num_buckets, dtype=torch.int32, device=self.torch_device)
         lib = _lib.load()
         tb = ct.c_size_t()
         wb = ct.c_size_t()
-        check(lib.adlhip_radix_sort_scratch_bytes(st.device._h, 0, n, ct.byref(tb), ct.byref(wb)), "scratch_bytes")
+        check(lib.adlhip_radix_sort_scratch_bytes(st.device._h, 1 if pairs else 0, n, ct.byref(tb), ct.byref(wb)), "scratch_bytes")
         if st.work is None or st.work.getSize() < wb.value:
             if st.work is not None:
                 DeviceUtils.waitForCompletion(st.device)
                 st.work.release()
             st.work = Buffer(st.device, wb.value + wb.value // 8, np.uint8)
-        check(lib.adlhip_partition_msb_u32(st.device._h, ct.c_void_p(keys.data_ptr()), ct.c_void_p(out.data_ptr()),
-                                           ct.c_void_p(counts.data_ptr()), st.work.ptr(), st.work.getSize(),
-                                           n, int(num_buckets)), "adlhip_partition_msb_u32")
+        fn = lib.adlhip_partition_msb_kv32 if pairs else lib.adlhip_partition_msb_u32
+        check(fn(st.device._h, ct.c_void_p(keys.data_ptr()), ct.c_void_p(out.data_ptr()), ct.c_void_p(counts.data_ptr()),
+                 st.work.ptr(), st.work.getSize(), n, int(num_buckets)), "adlhip_partition_msb")
         return out, counts
 
+
     def local_sort(self, keys):
-        """In-place ascending sort of an int32 CUDA tensor holding u32 bit patterns, on the stage of the
-        scope we are in."""
+        """In-place ascending sort (by key, stable) of an int32 CUDA tensor holding u32 bit patterns or an int64
+        CUDA tensor holding {key, value} pairs, on the stage of the scope we are in."""
         n = keys.numel()
         if n:
             st = self._cur
-            if n > st.reserved:
+            nbytes = n * keys.element_size()
+            if nbytes > st.reserved:
                 # received counts jitter from batch to batch: size the scratch with headroom once instead of
                 # re-growing it (a device-wide sync + hipMalloc) whenever a slightly larger batch arrives
-                st.reserved = n + n // 16 + 1024
-                st.pprims.reserve(st.device, ELEM_U32, st.reserved)
+                cap = n + n // 16 + 1024
+                st.reserved = cap * keys.element_size()
+                st.pprims.reserve(st.device, ELEM_U32 if keys.dtype == torch.int32 else ELEM_KV32, cap)
             st.pprims.radixSort(st.device, self._wrap(st.device, keys), n)
         return keys
 
 
 class ShardedRadixSort:
-    """Host logic of the MSB-bucket sharded sort.  `backend` supplies empty / partition_msb / local_sort
+    """Host logic of the MSB-bucket sharded sort of u32 keys (int32 tensors) or {u32 key, u32 value} pairs (int64
+    tensors, key in the low dword; stable: equal keys keep the order (source rank, position in the rank's shard)).
+    `backend` supplies empty / partition_msb / local_sort
     (and, for sort_stream, the pipeline plumbing: exchange_scope / sort_scope / event / wait /
     recv_buffer / part_buffer / pipeline_depth)."""
 
@@ -268,7 +279,7 @@ class ShardedRadixSort:
         dist.all_gather_into_tensor(matrix, counts, group=self.group)
         send_splits, recv_splits = self._splits(matrix)
         mark()
-        recv = be.empty(sum(recv_splits))
+        recv = be.empty(sum(recv_splits), keys.dtype)
         dist.all_to_all_single(recv, part, recv_splits, send_splits, group=self.group)
         mark()
         be.local_sort(recv)
@@ -298,7 +309,7 @@ class ShardedRadixSort:
         for i, keys in enumerate(batches):
             slot = i % depth
             with be.exchange_scope(after_caller=True):
-                part, counts = be.partition_msb(keys, G, out=be.part_buffer(slot, keys.numel()))
+                part, counts = be.partition_msb(keys, G, out=be.part_buffer(slot, keys.numel(), keys.dtype))
                 matrix = torch.empty(G * G, dtype=counts.dtype, device=counts.device)
                 dist.all_gather_into_tensor(matrix, counts, group=self.group)
             out = None
@@ -308,7 +319,7 @@ class ShardedRadixSort:
             with be.exchange_scope():
                 send_splits, recv_splits = self._splits(matrix)
                 be.wait(sorted_ev[slot])        # the slot's previous occupant has been sorted (and handed out)
-                recv = be.recv_buffer(slot, sum(recv_splits))
+                recv = be.recv_buffer(slot, sum(recv_splits), keys.dtype)
                 dist.all_to_all_single(recv, part, recv_splits, send_splits, group=self.group)
                 arrived = (recv, be.event(), slot)
             if out is not None:

@@ -28,8 +28,8 @@ class NumpyBackend:
         self._scope = "caller"
         self._slots = {}
 
-    def empty(self, n):
-        return torch.empty(int(n), dtype=torch.int32)
+    def empty(self, n, dtype=torch.int32):
+        return torch.empty(int(n), dtype=dtype)
 
     @contextlib.contextmanager
     def exchange_scope(self, after_caller=False):
@@ -54,27 +54,29 @@ class NumpyBackend:
     def wait(self, ev):
         pass
 
-    def _slot(self, kind, slot, n):
-        t = self._slots.get((kind, slot))
+    def _slot(self, kind, slot, n, dtype):
+        t = self._slots.get((kind, slot, dtype))
         if t is None or t.numel() < n:
-            t = self._slots[(kind, slot)] = torch.empty(int(n) + 7, dtype=torch.int32)
+            t = self._slots[(kind, slot, dtype)] = torch.empty(int(n) + 7, dtype=dtype)
         return t[:n]
 
-    def recv_buffer(self, slot, n):
+    def recv_buffer(self, slot, n, dtype=torch.int32):
         assert 0 <= slot < self.pipeline_depth
-        return self._slot("recv", slot, n)
+        return self._slot("recv", slot, n, dtype)
 
-    def part_buffer(self, slot, n):
-        return self._slot("part", slot, n)
+    def part_buffer(self, slot, n, dtype=torch.int32):
+        return self._slot("part", slot, n, dtype)
 
     def partition_msb(self, keys, num_buckets, out=None):
         self.log.append(("partition", self._scope))
-        k = keys.numpy().view(np.uint32)
+        pairs = keys.dtype == torch.int64
+        k = keys.numpy().view(np.uint64 if pairs else np.uint32)
+        key32 = (k & np.uint64(0xffffffff)).astype(np.uint32) if pairs else k
         lg = num_buckets.bit_length() - 1
-        bucket = (k >> np.uint32(32 - lg)).astype(np.int64) if lg else np.zeros(k.size, dtype=np.int64)
+        bucket = (key32 >> np.uint32(32 - lg)).astype(np.int64) if lg else np.zeros(k.size, dtype=np.int64)
         order = np.argsort(bucket, kind="stable")
         counts = np.bincount(bucket, minlength=num_buckets).astype(np.int32)
-        res = torch.from_numpy(k[order].view(np.int32).copy())
+        res = torch.from_numpy(k[order].view(np.int64 if pairs else np.int32).copy())
         if out is not None:
             out.copy_(res)
             res = out
@@ -83,8 +85,12 @@ class NumpyBackend:
     def local_sort(self, keys):
         import oracle
         self.log.append(("sort", self._scope))
-        k = keys.numpy().view(np.uint32)
-        k[:] = oracle.sort_u32(k)
+        if keys.dtype == torch.int64:
+            k = keys.numpy().view(np.uint64)
+            k[:] = oracle.sort_kv32(k)
+        else:
+            k = keys.numpy().view(np.uint32)
+            k[:] = oracle.sort_u32(k)
         return keys
 
 
@@ -109,7 +115,7 @@ def _worker(rank, world, port, n_per_rank, skew, out_dir):
         dist.destroy_process_group()
 
 
-def _stream_worker(rank, world, port, sizes, out_dir):
+def _stream_worker(rank, world, port, sizes, out_dir, pairs=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -124,12 +130,16 @@ def _stream_worker(rank, world, port, sizes, out_dir):
             keys = oracle.keys_u32(n, seed=500 + b, first_index=rank * n)
             if b % 2:   # every other batch skewed: ragged splits that change from batch to batch
                 keys = np.where(np.arange(n) % 7 != 0, keys >> np.uint32(2 + b % 3), keys).astype(np.uint32)
+            if pairs:   # {key, value = global index}; few distinct keys in the skewed batches: stability is visible
+                if b % 2:
+                    keys = (keys & np.uint32(0xe0000003)).astype(np.uint32)
+                keys = keys.astype(np.uint64) | ((np.arange(n, dtype=np.uint64) + np.uint64(rank * n)) << np.uint64(32))
             np.save(os.path.join(out_dir, "in_%d_%d.npy" % (b, rank)), keys)
-            batches.append(torch.from_numpy(keys.view(np.int32).copy()))
+            batches.append(torch.from_numpy(keys.view(np.int64 if pairs else np.int32).copy()))
         got = 0
         for b, res in enumerate(sorter.sort_stream(batches)):
             # a result must be intact when it is handed out AND stay intact while later batches are in flight
-            np.save(os.path.join(out_dir, "out_%d_%d.npy" % (b, rank)), res.numpy().view(np.uint32))
+            np.save(os.path.join(out_dir, "out_%d_%d.npy" % (b, rank)), res.numpy().view(np.uint64 if pairs else np.uint32))
             got += 1
         assert got == len(sizes)
         # schedule: batch i+1's partition is issued (exchange stage) before batch i's local sort (sort stage)
@@ -177,6 +187,19 @@ def test_pipelined_sort_stream_world2_gloo(tmp_path):
         assert np.array_equal(np.concatenate(outs), oracle.sort_u32(np.concatenate(ins))), "batch %d" % b
         for r, o in enumerate(outs):
             assert o.size == 0 or ((o >> np.uint32(31)) == r).all()
+
+
+def test_pipelined_key_value_sort_stream_world2_gloo(tmp_path):
+    """{key, value} pairs through the same pipeline: globally sorted by key, STABLE (equal keys keep the order
+    (source rank, position in the shard) = the order of the concatenated input)."""
+    import oracle
+    world = 2
+    sizes = [30011, 777, 0, 41234]
+    mp.spawn(_stream_worker, args=(world, _free_port(), sizes, str(tmp_path), True), nprocs=world, join=True)
+    for b in range(len(sizes)):
+        ins = [np.load(tmp_path / ("in_%d_%d.npy" % (b, r))) for r in range(world)]
+        outs = [np.load(tmp_path / ("out_%d_%d.npy" % (b, r))) for r in range(world)]
+        assert np.array_equal(np.concatenate(outs), oracle.sort_kv32(np.concatenate(ins))), "batch %d" % b
 
 
 def test_sort_stream_without_process_group_is_a_plain_local_sort():

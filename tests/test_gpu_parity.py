@@ -444,6 +444,12 @@ def test_msb_partition_and_simulated_exchange():
                 assert np.array_equal(p, k[order] if G > 1 else k), G      # one bucket: a plain copy
                 parts.append(p)
                 counts.append(c)
+                # {key, value} pairs: same partition by the key's top bits, values travel along
+                pr = k.astype(np.uint64) | (np.arange(n, dtype=np.uint64) << np.uint64(32))
+                pp_, pc_ = be.partition_msb(torch.from_numpy(pr.view(np.int64).copy()).cuda(), G)
+                torch.cuda.synchronize()
+                assert np.array_equal(pc_.cpu().numpy().astype(np.int64), c), G
+                assert np.array_equal(pp_.cpu().numpy().view(np.uint64), pr[order] if G > 1 else pr), G
             if G <= 8:
                 # what all_to_all_single would deliver: rank g receives, in source-rank order, every
                 # shard's segment g; then sorts locally
@@ -506,9 +512,39 @@ def test_pipelined_sort_stream_over_rccl_one_rank():
             check_one(*item)
             checked += 1
         assert checked == len(sizes)
+        # stage discipline: in the pipeline the partition runs on the EXCHANGE stage's handle (its stream carries the
+        # collectives that consume the counts), the local sort on the SORT stage's, nothing on the caller's
+        for st in (be._caller, be._exchange, be._sorting):
+            st.device.toggleProfiling(True)
+            st.device.profile(reset=True)
+        for res in sorter.sort_stream(dev_in[:3], force_exchange=True):
+            pass
+        torch.cuda.synchronize()
+        prof = [st.device.profile(reset=True) for st in (be._caller, be._exchange, be._sorting)]
+        for st in (be._caller, be._exchange, be._sorting):
+            st.device.toggleProfiling(False)
+        assert not prof[0], prof[0]
+        assert "fill_u32" in prof[1] and not any(k.startswith(("onesweep", "scatter", "small_sort")) for k in prof[1]), prof[1]
+        assert any(k.startswith(("onesweep", "scatter", "small_sort")) for k in prof[2]) and "fill_u32" not in prof[2], prof[2]
         # the serial driver gives the same answer through the same collectives
         r = sorter.sort(dev_in[1].clone(), force_exchange=True)
         assert np.array_equal(r.cpu().numpy().view(np.uint32), oracle.sort_u32(ins[1]))
+        # {key, value} pairs (int64 tensors) through both drivers: stable by key
+        pin = []
+        for b, n in enumerate((500009, 0, 1 << 20, 70001)):
+            k = oracle.keys_u32(n, seed=40 + b)
+            if b == 0:
+                k &= np.uint32(0xff0000ff)
+            pin.append(k.astype(np.uint64) | (np.arange(n, dtype=np.uint64) << np.uint64(32)))
+        pdev = [torch.from_numpy(p.view(np.int64).copy()).cuda() for p in pin]
+        prev = None
+        for b, res in enumerate(sorter.sort_stream(pdev, force_exchange=True)):
+            if prev is not None:
+                assert np.array_equal(prev[1].cpu().numpy().view(np.uint64), oracle.sort_kv32(pin[prev[0]])), prev[0]
+            prev = (b, res)
+        assert np.array_equal(prev[1].cpu().numpy().view(np.uint64), oracle.sort_kv32(pin[prev[0]]))
+        r = sorter.sort(pdev[0], force_exchange=True)
+        assert np.array_equal(r.cpu().numpy().view(np.uint64), oracle.sort_kv32(pin[0]))
     finally:
         if be is not None:
             be.close()
