@@ -551,6 +551,76 @@ def test_pipelined_sort_stream_over_rccl_one_rank():
         dist.destroy_process_group()
 
 
+def _two_rank_worker(rank, world, port, out_dir):
+    """Two processes on ONE GPU: the real HipBackend (partition with G = 2, ragged exchange, streams, slots), with the
+    two collectives staged through the host over gloo -- RCCL refuses two ranks on one device, and everything else is
+    what runs on a multi-GPU node."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    real_ag, real_a2a = dist.all_gather_into_tensor, dist.all_to_all_single
+
+    def staged_all_gather(out, inp, group=None):
+        torch.cuda.current_stream().synchronize()
+        o = torch.empty(out.shape, dtype=out.dtype)
+        real_ag(o, inp.cpu(), group=group)
+        out.copy_(o)
+
+    def staged_all_to_all(out, inp, out_splits, in_splits, group=None):
+        torch.cuda.current_stream().synchronize()
+        o = torch.empty(out.shape, dtype=out.dtype)
+        real_a2a(o, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(o)
+
+    dist.all_gather_into_tensor, dist.all_to_all_single = staged_all_gather, staged_all_to_all
+    from oclradixsort_amd.dist import HipBackend, ShardedRadixSort
+    be = HipBackend(0)
+    try:
+        sorter = ShardedRadixSort(be)
+        sizes = [700001, 1 << 20, 333, 0, 250007, 1 << 19]
+        dev_in = []
+        for b, n in enumerate(sizes):
+            k = oracle.keys_u32(n, seed=70 + b, first_index=rank * n)
+            if b % 2:   # skewed: almost everything goes to rank 0
+                k = np.where(np.arange(n) % 9 != 0, k >> np.uint32(1 + b), k).astype(np.uint32)
+            np.save(os.path.join(out_dir, "in_%d_%d.npy" % (b, rank)), k)
+            dev_in.append(torch.from_numpy(k.view(np.int32).copy()).cuda())
+        for b, res in enumerate(sorter.sort_stream(dev_in)):
+            np.save(os.path.join(out_dir, "out_%d_%d.npy" % (b, rank)), res.cpu().numpy().view(np.uint32))
+        # pairs through the serial driver
+        n = 400003
+        k = (oracle.keys_u32(n, seed=5, first_index=rank * n) & np.uint32(0xc000000f)).astype(np.uint64)
+        pr = k | ((np.arange(n, dtype=np.uint64) + np.uint64(rank * n)) << np.uint64(32))
+        np.save(os.path.join(out_dir, "kvin_%d.npy" % rank), pr)
+        r = sorter.sort(torch.from_numpy(pr.view(np.int64).copy()).cuda())
+        np.save(os.path.join(out_dir, "kvout_%d.npy" % rank), r.cpu().numpy().view(np.uint64))
+    finally:
+        be.close()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_with_host_staged_collectives(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    mp.spawn(_two_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for b in range(6):
+        ins = [np.load(tmp_path / ("in_%d_%d.npy" % (b, r))) for r in range(world)]
+        outs = [np.load(tmp_path / ("out_%d_%d.npy" % (b, r))) for r in range(world)]
+        assert np.array_equal(np.concatenate(outs), oracle.sort_u32(np.concatenate(ins))), "batch %d" % b
+        for r, o in enumerate(outs):
+            assert o.size == 0 or ((o >> np.uint32(31)) == r).all()
+    kin = [np.load(tmp_path / ("kvin_%d.npy" % r)) for r in range(world)]
+    kout = [np.load(tmp_path / ("kvout_%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(np.concatenate(kout), oracle.sort_kv32(np.concatenate(kin)))
+
+
 def test_generated_keys_match_the_oracle_generator(dev):
     n = 100001
     for kind, dtype, want in ((0, np.uint32, oracle.keys_u32(n, 123, 77)), (1, np.uint64, oracle.pairs_kv32(n, 123, 77)),
