@@ -70,7 +70,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=N_KEYS, help="keys per GPU (default 64Mi = BASELINE config #2)")
+    ap.add_argument("--n", "--keys-per-gpu", dest="n", type=int, default=int(os.environ.get("ADLHIP_BENCH_N", N_KEYS)),
+                    help="keys per GPU (default 64Mi = BASELINE config #2; under torch.distributed.run use --keys-per-gpu "
+                         "or ADLHIP_BENCH_N: its own parser claims --n)")
     ap.add_argument("--algo", type=int, default=None, help="sort.algo override (0 onesweep, 1 three-kernel)")
     ap.add_argument("--digit-bits", type=int, default=None, help="sort.digit_bits override (8 or 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,10 +93,34 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the device path has no CPU fallback")
+    # ADLHIP_BENCH_REHEARSE=1 (development only, never a benchmark number): run the N > 1 code path with all ranks on GPU 0
+    # and the collectives staged through the host over gloo -- RCCL refuses two ranks on one device, and a 1-GPU box is
+    # all there is to rehearse on.  Everything else (partition, splits, streams, slots, verification) is the real thing.
+    rehearse = os.environ.get("ADLHIP_BENCH_REHEARSE") == "1" and world > 1
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+            real_ag, real_a2a = dist.all_gather_into_tensor, dist.all_to_all_single
+
+            def staged_all_gather(out, inp, group=None):
+                torch.cuda.current_stream().synchronize()
+                o = torch.empty(out.shape, dtype=out.dtype)
+                real_ag(o, inp.cpu(), group=group)
+                out.copy_(o)
+
+            def staged_all_to_all(out, inp, out_splits, in_splits, group=None):
+                torch.cuda.current_stream().synchronize()
+                o = torch.empty(out.shape, dtype=out.dtype)
+                real_a2a(o, inp.cpu(), out_splits, in_splits, group=group)
+                out.copy_(o)
+
+            dist.all_gather_into_tensor, dist.all_to_all_single = staged_all_gather, staged_all_to_all
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n = args.n
     K, W = args.steps, args.warmup
@@ -336,6 +362,8 @@ def main():
             "sort_roofline_frac_96B_per_key": (value / world) * ALGO_BYTES_PER_KEY_SORT / HBM_PEAK_GBS,
         }
         line.update(out)
+        if rehearse:
+            line["data"] = "REHEARSAL on one GPU with host-staged collectives: not a benchmark number"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], _ = cpu_baseline(n)
     else:
