@@ -252,7 +252,8 @@ def main():
             be.setParam("sort.algo", args.algo)
         if args.digit_bits is not None:
             be.setParam("sort.digit_bits", args.digit_bits)
-        sorter = ShardedRadixSort(be)
+        # ADLHIP_BENCH_FORCE_BUCKETS=8 with ADLHIP_BENCH_FORCE_DIST=1: pay an 8-rank partition pass on the 1-GPU rehearsal
+        sorter = ShardedRadixSort(be, rehearse_buckets=int(os.environ.get("ADLHIP_BENCH_FORCE_BUCKETS", "0")) if force_dist else 0)
         inputs = []
         for i in range(K + W):
             t = be.empty(n)

@@ -239,9 +239,12 @@ class ShardedRadixSort:
     (and, for sort_stream, the pipeline plumbing: exchange_scope / sort_scope / event / wait /
     recv_buffer / part_buffer / pipeline_depth)."""
 
-    def __init__(self, backend, group=None):
+    def __init__(self, backend, group=None, rehearse_buckets=0):
         self.backend = backend
         self.group = group
+        # development aid: partition into this many buckets even if the world is smaller (the counts are folded back
+        # to one per rank), so that a 1-GPU box pays the partition pass an 8-GPU rank would pay
+        self.rehearse_buckets = int(rehearse_buckets)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         if self.world & (self.world - 1):
@@ -249,6 +252,15 @@ class ShardedRadixSort:
         if self.world > 256:
             raise ValueError("at most 256 ranks")
         self.last_splits = None
+
+    def _partition(self, keys, out=None):
+        """Partition by the top bits into one contiguous segment per rank; returns (partitioned, counts[G])."""
+        G = self.world
+        B = max(G, self.rehearse_buckets)
+        part, counts = self.backend.partition_msb(keys, B, out=out)
+        if B != G:
+            counts = counts.view(G, B // G).sum(dim=1, dtype=counts.dtype)
+        return part, counts
 
     def _splits(self, matrix):
         """Count matrix (row r = rank r's send counts) -> (send_splits, recv_splits) of this rank.  The
@@ -272,7 +284,7 @@ class ShardedRadixSort:
             return be.local_sort(keys)
         mark = (lambda: marks.append(be.event(True))) if marks is not None else (lambda: None)
         mark()
-        part, counts = be.partition_msb(keys, G)
+        part, counts = self._partition(keys)
         mark()
         # one collective for all split sizes: row r of the matrix = rank r's send counts
         matrix = torch.empty(G * G, dtype=counts.dtype, device=counts.device)
@@ -309,7 +321,7 @@ class ShardedRadixSort:
         for i, keys in enumerate(batches):
             slot = i % depth
             with be.exchange_scope(after_caller=True):
-                part, counts = be.partition_msb(keys, G, out=be.part_buffer(slot, keys.numel(), keys.dtype))
+                part, counts = self._partition(keys, out=be.part_buffer(slot, keys.numel(), keys.dtype))
                 matrix = torch.empty(G * G, dtype=counts.dtype, device=counts.device)
                 dist.all_gather_into_tensor(matrix, counts, group=self.group)
             out = None
