@@ -406,7 +406,7 @@ int three_kernel_pass(adlhip_device* d, const Buf& src, const Buf& dst, void* wo
 // ---- onesweep --------------------------------------------------------------------------------
 
 // work buffer layout (onesweep):
-//   [ctrl   : per pass 16 chain tickets (64 B); 16 passes = 1024 B]
+//   [ctrl   : per pass 16 chain tickets, one 128-byte line each (2 KiB); 16 passes = 32 KiB]
 //   [tables : 16 x PassTable]
 //   [joint  : joint histograms of all passes (<= 16 passes x 16 chains x 256 bins)]
 //   [partial: hist_wgs x total_bins u32]
@@ -437,7 +437,7 @@ OnesweepLayout onesweep_layout(const adlhip_device* d, size_t n, int max_passes,
     OnesweepLayout L;
     L.hist_wgs = hist_wgs_for(d, n);
     L.off_ctrl = 0;
-    L.off_tables = 1024;
+    L.off_tables = (size_t)adlhip::kTicketVecs * 16;
     L.off_joint = L.off_tables + sizeof(adlhip::PassTable) * adlhip::kMaxPasses;
     L.off_part = align_up(L.off_joint + (size_t)kMaxJointBins * 4, 256);
     L.off_status = align_up(L.off_part + (size_t)L.hist_wgs * kMaxJointBins * 4, 256);
@@ -538,8 +538,8 @@ int onesweep_sort(adlhip_device* d, Buf data, Buf tmp, void* work, size_t n, con
     Buf dst = tmp;
     for (int i = 0; i < P; ++i) {
         uint32_t* st = status + (size_t)i * rows * 256;
-        rc = (plan[i].nbits == 8) ? dispatch_onesweep<Buf, 8>(d, src, dst, tables + i, st, ctrl + i * 16, n, plan[i].start_bit)
-                                  : dispatch_onesweep<Buf, 4>(d, src, dst, tables + i, st, ctrl + i * 16, n, plan[i].start_bit);
+        rc = (plan[i].nbits == 8) ? dispatch_onesweep<Buf, 8>(d, src, dst, tables + i, st, ctrl + i * 16 * adlhip::kTicketStride, n, plan[i].start_bit)
+                                  : dispatch_onesweep<Buf, 4>(d, src, dst, tables + i, st, ctrl + i * 16 * adlhip::kTicketStride, n, plan[i].start_bit);
         if (rc) return rc;
         std::swap(src, dst);
     }

@@ -47,10 +47,15 @@
 
 namespace adlhip {
 
+constexpr int kMaxPassesFwd = 16;
 constexpr int kChains = 16;          // independent look-back chains per pass (top nibble of the previous digit)
+constexpr int kTicketStride = 32;    // u32 words between two chains' ticket counters: one 128-byte line each (sixteen counters
+                                     // in ONE line queue every ticket of a pass on the same atomic unit)
+constexpr int kTicketVecs = kMaxPassesFwd * kChains * kTicketStride * 4 / 16;   // 16-byte vectors of the ticket area
 constexpr int kHistNT = 1024;
 constexpr uint32_t kHistChunk = 64 * 1024;   // minimum elements per histogram workgroup
 constexpr int kMaxPasses = 16;
+static_assert(kMaxPasses == kMaxPassesFwd, "ticket area");
 
 struct PassDesc {
     int num_passes;
@@ -101,7 +106,8 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
     // drain under the key stream, instead of two memset launches in front of every sort.
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
-        if (blockIdx.x == 0 && tid < 64) tickets[tid] = z;
+        if (blockIdx.x == 0)
+            for (int i = tid; i < kTicketVecs; i += kHistNT) tickets[i] = z;
         const size_t stride = (size_t)gridDim.x * kHistNT;
         for (size_t i = (size_t)blockIdx.x * kHistNT + (size_t)tid; i < status_vecs; i += stride) status[i] = z;
     }
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTab
         uint32_t v = 0u;
         if (lane <= kChains) v = table->tile_start[lane];
         else if (lane <= 2 * kChains + 1) v = table->chunk_start[lane - (kChains + 1)];
-        else if (lane == 2 * kChains + 2) v = atomicAdd(&tickets[c0], 1u);
+        else if (lane == 2 * kChains + 2) v = atomicAdd(&tickets[c0 * (uint32_t)kTicketStride], 1u);
         auto at = [&](uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
         uint32_t chain = c0;
         uint32_t index = at(2 * kChains + 2);
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTab
                 const uint32_t tiles_c = at(c + 1u) - at(c);
                 if (tiles_c == 0u) continue;
                 uint32_t i = 0u;
-                if (lane == 0) i = atomicAdd(&tickets[c], 1u);
+                if (lane == 0) i = atomicAdd(&tickets[c * (uint32_t)kTicketStride], 1u);
                 i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
                 if (i < tiles_c) { chain = c; index = i; break; }
             }
