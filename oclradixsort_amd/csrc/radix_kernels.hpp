@@ -217,7 +217,7 @@ struct SoaIO {
 
 // Buffer stores need every element of a destination array within reach of a 32-bit byte offset; they are USED
 // for arrays up to 256 MiB, where they measured faster than pointer stores (64Mi u32 keys: +2.8 %, 32Mi: +3.5 %);
-// at 512 MiB the two are level and at 1 GiB pointer stores win by 1.3 % (profiles/r1_bufstore_ab.txt).
+// at 512 MiB the two are level and at 1 GiB pointer stores win by 1.3 % (profiles/r1_pass_kernel_experiments.txt).
 template <typename IO>
 __device__ __forceinline__ bool dst_fits32(uint32_t n)
 {
