@@ -372,11 +372,11 @@ int dispatch_scatter(adlhip_device* d, const Buf& src, const Buf& dst, const uin
     ADLHIP_DISPATCH_TILE(launch_scatter, Buf, NBITS, d, src, dst, table, totals, n, g, start_bit)
 }
 
-// three-kernel pass with at most this many workgroups: the scatter kernel scans the raw count table itself
-// (each workgroup reads 256 x n_wgs words) and the table-scan launch is dropped -- 12 -> 8 dependent launches per
-// 32-bit sort for n <= 64 Ki keys (4 Ki-key tiles): 32 Ki keys 36.5 -> 27.9 us, 64 Ki 36.5 -> 29.5 us.  Measured
-// level at 32 workgroups and a loss beyond (256 Ki keys: 45.6 vs 38.7 us).
-constexpr uint32_t kScanInScatterMaxWgs = 16;
+// three-kernel pass with at most this many workgroups: the count kernel leaves its raw counts workgroup-major and the
+// scatter kernel sums its column itself (16 or 64 independent coalesced loads per thread), so the table-scan launch is
+// dropped -- 12 -> 8 dependent launches per 32-bit sort.  Same-session A/B (ADLHIP_FUSED_SCAN_MAX = 0 / 16 / 64):
+// 32 Ki keys 35.8 -> 26.5 us; 64 Ki + 1 .. 128 Ki keys 38.3 -> 36.0 / 37.2 -> 34.5 us; 200000 .. 256 Ki keys level.
+constexpr uint32_t kScanInScatterMaxWgs = 64;
 
 template <typename Buf, int NBITS>
 int three_kernel_pass(adlhip_device* d, const Buf& src, const Buf& dst, void* work, size_t n, int start_bit,
@@ -388,13 +388,14 @@ int three_kernel_pass(adlhip_device* d, const Buf& src, const Buf& dst, void* wo
     uint32_t* table = reinterpret_cast<uint32_t*>(work);
     uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + table_bytes(d, n, kMinTile));
     const uint32_t elems_per_wg = g.tiles_per_wg * g.tile;
+    static const uint32_t fused_max = getenv("ADLHIP_FUSED_SCAN_MAX") ? (uint32_t)atoi(getenv("ADLHIP_FUSED_SCAN_MAX")) : kScanInScatterMaxWgs;
+    const bool fused = !need_totals && g.n_wgs <= std::min<uint32_t>(fused_max, 64u);
     int rc = launch(d, kernel_name<Buf, NBITS>("count"), [&] {
         hipLaunchKernelGGL((adlhip::radix_count_kernel<key_t, NBITS, kCountNT>), dim3(g.n_wgs), dim3(kCountNT), 0, d->stream,
-                           src.keys(), table, (uint32_t)n, (int)g.n_wgs, start_bit, elems_per_wg);
+                           src.keys(), table, (uint32_t)n, (int)g.n_wgs, start_bit, elems_per_wg, fused ? 1 : 0);
     });
     if (rc) return rc;
-    if (!need_totals && g.n_wgs <= kScanInScatterMaxWgs)
-        return dispatch_scatter<Buf, NBITS>(d, src, dst, table, nullptr, n, g, start_bit);
+    if (fused) return dispatch_scatter<Buf, NBITS>(d, src, dst, table, nullptr, n, g, start_bit);
     rc = launch(d, "scan_table", [&] {
         hipLaunchKernelGGL((adlhip::radix_scan_table_kernel<256>), dim3(1 << NBITS), dim3(256), 0, d->stream, table,
                            totals, (int)g.n_wgs);

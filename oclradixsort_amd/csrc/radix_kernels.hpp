@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace adlhip {
 
@@ -478,7 +479,7 @@ __device__ __forceinline__ void sort_scatter_tile(const IO& io, uint32_t tile_ba
 template <typename E, int NBITS, int NT>
 __global__ __launch_bounds__(NT) void radix_count_kernel(const E* __restrict__ src,
                                                          uint32_t* __restrict__ table, uint32_t n,
-                                                         int n_wgs, int start_bit, uint32_t elems_per_wg)
+                                                         int n_wgs, int start_bit, uint32_t elems_per_wg, int wg_major)
 {
     constexpr int BINS = 1 << NBITS;
     constexpr int NW = NT / 64;
@@ -557,7 +558,8 @@ __global__ __launch_bounds__(NT) void radix_count_kernel(const E* __restrict__ s
 #pragma unroll
             for (int c = 0; c < COPIES; ++c) sum += hist[c * BINS + tid];
         }
-        table[(size_t)tid * n_wgs + wg] = sum;
+        // wg_major (few workgroups, the scatter kernel scans the raw counts itself): one coalesced row per workgroup
+        table[wg_major ? (size_t)wg * BINS + tid : (size_t)tid * n_wgs + wg] = sum;
     }
 }
 
@@ -599,22 +601,28 @@ __global__ __launch_bounds__(NT) void radix_scatter_kernel(IO io, const uint32_t
     const uint32_t wg = blockIdx.x;
 
     // digit bases = exclusive scan of the digit totals; carry = base + scanned table entry.
-    // totals == nullptr (few workgroups, launch-bound sizes): `table` holds the RAW counts and thread b scans its own
-    // row here -- n_wgs contiguous words -- which saves the table-scan launch and its kernel boundary (~2 us per pass at 16 workgroups;
-    // level at 32, a loss beyond: the row walk is a chain of memory latencies, the separate scan kernel one parallel sweep).
+    // totals == nullptr (few workgroups, launch-bound sizes): `table` holds the RAW counts, workgroup-major
+    // (table[wg][digit]), and thread b sums its column here -- n_wgs coalesced, independent loads -- which saves the
+    // table-scan launch and its kernel boundary.
     uint32_t tot_b = 0u, pre_b = 0u;
     if (tid < C::BINS) {
         if (totals) {
             tot_b = totals[tid];
             pre_b = table[(size_t)tid * n_wgs + wg];
         } else {
-            const uint32_t* row = table + (size_t)tid * n_wgs;
-#pragma unroll 16
-            for (int j = 0; j < n_wgs; ++j) {   // n_wgs <= 16 here: one batch of independent loads
-                const uint32_t v = row[j];
-                tot_b += v;
-                pre_b += (j < (int)wg) ? v : 0u;
-            }
+            // fixed trip counts (16, or 64: n_wgs <= 64 here), every load independent of the others: one or two batches
+            // of loads in flight instead of a remainder loop that pays one memory latency per workgroup
+            auto walk = [&](auto trips) {
+#pragma unroll
+                for (int j = 0; j < decltype(trips)::value; ++j) {
+                    const int jj = j < n_wgs ? j : n_wgs - 1;
+                    const uint32_t v = table[(size_t)jj * C::BINS + tid];
+                    tot_b += (j < n_wgs) ? v : 0u;
+                    pre_b += (j < (int)wg) ? v : 0u;   // wg < n_wgs
+                }
+            };
+            if (n_wgs <= 16) walk(std::integral_constant<int, 16>());
+            else walk(std::integral_constant<int, 64>());
         }
     }
     const uint32_t base_b = block_excl_scan_u32<NT>(tot_b, s_wsum, nullptr);
