@@ -60,9 +60,19 @@ def cpu_baseline(n):
         times.append(dt)
         t_total += dt
     best = min(times)
+    cpu_model = "?"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": n / best / 1e9, "unit": "Gkeys/s", "cores": 1, "kind": kind,
-            "sample": "%d runs of the full %d-key u32 workload, best run %.3f s; host has %d logical cores"
-                      % (len(times), n, best, os.cpu_count() or 0)}, fn
+            "sample": "%d runs of the full %d-key u32 workload, best run %.3f s; host: %s, %d logical cores, 1 used "
+                      "(the reference's CPU sort is single-threaded)"
+                      % (len(times), n, best, cpu_model, os.cpu_count() or 0)}, fn
 
 
 def main():
