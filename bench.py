@@ -272,6 +272,7 @@ def main():
             # global index space: rank r owns indices [r*n, (r+1)*n) of step i's key sequence
             b.generate(n, seed=123 + i, firstIndex=rank * n)
             inputs.append(t)
+        be.reserve(n)   # slots and scratch of the pipeline: allocated before anything is timed, whatever W is
         torch.cuda.synchronize()
 
         def run(batches):

@@ -170,6 +170,28 @@ class HipBackend:
             pool[slot] = t
         return t[:n]
 
+    def reserve(self, n, dtype=torch.int32):
+        """Allocate everything a sort_stream over batches of about n elements per rank needs -- the receive and partition
+        slots, both stages' scratch -- now, so that the first batches do not pay for it (allocations sync the device)."""
+        n = int(n)
+        cap = n + n // 16 + 1024
+        for slot in range(self.pipeline_depth):
+            self.recv_buffer(slot, cap, dtype)
+            self.part_buffer(slot, n, dtype)
+        kind = ELEM_U32 if dtype == torch.int32 else ELEM_KV32
+        ex, so = self._stage("_exchange"), self._stage("_sorting")
+        if cap * torch.empty(0, dtype=dtype).element_size() > so.reserved:
+            so.reserved = cap * torch.empty(0, dtype=dtype).element_size()
+            so.pprims.reserve(so.device, kind, cap)
+        ct = self._ct
+        tb, wb = ct.c_size_t(), ct.c_size_t()
+        check(_lib.load().adlhip_radix_sort_scratch_bytes(ex.device._h, kind, n, ct.byref(tb), ct.byref(wb)), "scratch_bytes")
+        if ex.work is None or ex.work.getSize() < wb.value:
+            if ex.work is not None:
+                DeviceUtils.waitForCompletion(ex.device)
+                ex.work.release()
+            ex.work = Buffer(ex.device, wb.value + wb.value // 8, np.uint8)
+
     def recv_buffer(self, slot, n, dtype=torch.int32):
         """Persistent receive buffer of pipeline slot `slot`, at least n elements (view of exactly n)."""
         return self._slot_buffer(self._recv, slot, n, dtype)
