@@ -27,6 +27,14 @@
 
 #include <Tahoe/Math/Error.h>
 
+// Run a C-ABI call and assert on its status.  The call sits OUTSIDE the assertion expression, so it runs whatever ADLASSERT
+// is defined to (the reference's release build defines it to nothing, Tahoe/Math/Error.h:24-38).
+#define ADLHIP_CALL(expr)                \
+    do {                                 \
+        const int adlhip_rc_ = (expr);   \
+        ADLASSERT(adlhip_rc_ == 0);      \
+    } while (0)
+
 namespace adl {
 
 typedef unsigned long long u64;
@@ -139,7 +147,7 @@ struct DeviceHip : public Device {
     void release()
     {
         if (m_hip) {
-            ADLASSERT(adlhip_device_destroy(m_hip) == ADLHIP_SUCCESS);
+            ADLHIP_CALL(adlhip_device_destroy(m_hip));
             m_hip = 0;
         }
     }
@@ -182,23 +190,23 @@ struct DeviceHip : public Device {
         }
         return p;
     }
-    void freeBytes(void* p, u64 bytes) { ADLASSERT(adlhip_free(m_hip, p, (size_t)bytes) == ADLHIP_SUCCESS); }
-    void copyH2D(void* dst, const void* src, u64 bytes) const { ADLASSERT(adlhip_memcpy_h2d(m_hip, dst, src, (size_t)bytes) == 0); }
-    void copyD2H(void* dst, const void* src, u64 bytes) const { ADLASSERT(adlhip_memcpy_d2h(m_hip, dst, src, (size_t)bytes) == 0); }
-    void copyD2D(void* dst, const void* src, u64 bytes) const { ADLASSERT(adlhip_memcpy_d2d(m_hip, dst, src, (size_t)bytes) == 0); }
-    void clearBytes(void* p, u64 bytes) const { ADLASSERT(adlhip_memset(m_hip, p, 0, (size_t)bytes) == 0); }
-    void fillU32(void* p, unsigned int pattern, u64 count) const { ADLASSERT(adlhip_fill_u32(m_hip, p, pattern, (size_t)count) == 0); }
+    void freeBytes(void* p, u64 bytes) { ADLHIP_CALL(adlhip_free(m_hip, p, (size_t)bytes)); }
+    void copyH2D(void* dst, const void* src, u64 bytes) const { ADLHIP_CALL(adlhip_memcpy_h2d(m_hip, dst, src, (size_t)bytes)); }
+    void copyD2H(void* dst, const void* src, u64 bytes) const { ADLHIP_CALL(adlhip_memcpy_d2h(m_hip, dst, src, (size_t)bytes)); }
+    void copyD2D(void* dst, const void* src, u64 bytes) const { ADLHIP_CALL(adlhip_memcpy_d2d(m_hip, dst, src, (size_t)bytes)); }
+    void clearBytes(void* p, u64 bytes) const { ADLHIP_CALL(adlhip_memset(m_hip, p, 0, (size_t)bytes)); }
+    void fillU32(void* p, unsigned int pattern, u64 count) const { ADLHIP_CALL(adlhip_fill_u32(m_hip, p, pattern, (size_t)count)); }
     void fillPattern(void* p, const void* pattern, int patternBytes, u64 count) const
     {
-        ADLASSERT(adlhip_fill_pattern(m_hip, p, pattern, (size_t)patternBytes, (size_t)count) == 0);
+        ADLHIP_CALL(adlhip_fill_pattern(m_hip, p, pattern, (size_t)patternBytes, (size_t)count));
     }
     void* mapBytes(void* p, u64 bytes) const
     {
         void* h = 0;
-        ADLASSERT(adlhip_map(m_hip, p, (size_t)bytes, &h) == ADLHIP_SUCCESS);
+        ADLHIP_CALL(adlhip_map(m_hip, p, (size_t)bytes, &h));
         return h;
     }
-    void unmapBytes(void* p, void* host, u64 bytes) const { ADLASSERT(adlhip_unmap(m_hip, p, host, (size_t)bytes) == ADLHIP_SUCCESS); }
+    void unmapBytes(void* p, void* host, u64 bytes) const { ADLHIP_CALL(adlhip_unmap(m_hip, p, host, (size_t)bytes)); }
     adlhip_device* hip() const { return m_hip; }
 
     adlhip_device* m_hip;

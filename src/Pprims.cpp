@@ -78,7 +78,8 @@ void Pprims::radixSort(const adl::Device* device, const adl::Buffer<u32>& inout,
     }
     ADLASSERT((sortBits & 0x3) == 0);   // Pprims.cpp:330
     size_t tb = 0, wb = 0;
-    ADLASSERT(adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_U32, (size_t)n, &tb, &wb) == ADLHIP_SUCCESS);
+    const int rcq = adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_U32, (size_t)n, &tb, &wb);   // not inside the assertion: the call has side effects (tb, wb)
+    ADLASSERT(rcq == ADLHIP_SUCCESS);
     reserve(device, tb, wb);
     const int rc = adlhip_radix_sort_u32(device->hip(), inout.m_ptr, (u32*)m_tmp->m_ptr, m_work->m_ptr, (size_t)m_work->getSize(),
                                          (size_t)n, sortBits);
@@ -102,7 +103,8 @@ void Pprims::radixSort(const adl::Device* device, const adl::Buffer<uint2>& inou
     }
     ADLASSERT((sortBits & 0x3) == 0);
     size_t tb = 0, wb = 0;
-    ADLASSERT(adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_KV32, (size_t)n, &tb, &wb) == ADLHIP_SUCCESS);
+    const int rcq = adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_KV32, (size_t)n, &tb, &wb);   // not inside the assertion: the call has side effects (tb, wb)
+    ADLASSERT(rcq == ADLHIP_SUCCESS);
     reserve(device, tb, wb);
     const int rc = adlhip_radix_sort_kv32(device->hip(), inout.m_ptr, m_tmp->m_ptr, m_work->m_ptr, (size_t)m_work->getSize(),
                                           (size_t)n, sortBits);
@@ -118,7 +120,8 @@ void Pprims::radixSort(const adl::Device* device, const adl::Buffer<u64>& inout,
     if (!enableSortOnDevice(device)) return;
     ADLASSERT((sortBits & 0x3) == 0);
     size_t tb = 0, wb = 0;
-    ADLASSERT(adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_U64, (size_t)n, &tb, &wb) == ADLHIP_SUCCESS);
+    const int rcq = adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_U64, (size_t)n, &tb, &wb);   // not inside the assertion: the call has side effects (tb, wb)
+    ADLASSERT(rcq == ADLHIP_SUCCESS);
     reserve(device, tb, wb);
     const int rc = adlhip_radix_sort_u64(device->hip(), (uint64_t*)inout.m_ptr, (uint64_t*)m_tmp->m_ptr, m_work->m_ptr,
                                          (size_t)m_work->getSize(), (size_t)n, sortBits);
@@ -135,7 +138,8 @@ void Pprims::radixSort(const adl::Device* device, const adl::Buffer<u32>& keys, 
     if (!enableSortOnDevice(device)) return;
     ADLASSERT((sortBits & 0x3) == 0);
     size_t tb = 0, wb = 0;
-    ADLASSERT(adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_SOA32, (size_t)n, &tb, &wb) == ADLHIP_SUCCESS);
+    const int rcq = adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_SOA32, (size_t)n, &tb, &wb);   // not inside the assertion: the call has side effects (tb, wb)
+    ADLASSERT(rcq == ADLHIP_SUCCESS);
     reserve(device, 2 * tb, wb);   // scratch keys + scratch values, back to back
     const int rc = adlhip_radix_sort_soa32(device->hip(), keys.m_ptr, values.m_ptr, (u32*)m_tmp->m_ptr,
                                            (u32*)(m_tmp->m_ptr + tb), m_work->m_ptr, (size_t)m_work->getSize(), (size_t)n,
@@ -152,7 +156,8 @@ void Pprims::scan(const adl::Device* device, adl::Buffer<int>& dst, const adl::B
     }
     ADLASSERT(n >= 0);
     size_t wb = 0;
-    ADLASSERT(adlhip_scan_scratch_bytes(device->hip(), (size_t)n, &wb) == ADLHIP_SUCCESS);
+    const int rcq = adlhip_scan_scratch_bytes(device->hip(), (size_t)n, &wb);   // not inside the assertion: the call has side effects (tb, wb)
+    ADLASSERT(rcq == ADLHIP_SUCCESS);
     reserve(device, 0, wb);
     // sumOut is filled by a stream-ordered copy, valid after the caller's waitForCompletion -- the reference
     // reads it back with a non-blocking read as well (Pprims.cpp:164-167)
