@@ -130,6 +130,9 @@ def main():
 
             dist.all_gather_into_tensor, dist.all_to_all_single = staged_all_gather, staged_all_to_all
         else:
+            # RCCL's kernels share the CUs with the local sort of the previous batch: let them in first (the exchange is the
+            # stage with the scarcer resource, the xGMI links)
+            os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n = args.n
