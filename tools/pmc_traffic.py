@@ -26,8 +26,10 @@ traffic = int(fetch_kb * 1024 * 2.0 + write_kb * 1024)
 json.dump({
     "kernel": kname, "profile_name": "onesweep_u32_8b", "keys_per_launch": n, "launches_averaged": min(nf, nw),
     "FETCH_SIZE_kb": round(fetch_kb, 1), "WRITE_SIZE_kb": round(write_kb, 1), "fetch_correction": 2.0,
-    "correction_note": "gfx950: FETCH_SIZE reports half of the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM); "
-                       "2 x FETCH_SIZE vs %.1f MB of keys + status rows" % (n * 4 / 1e6),
+    "correction_note": "gfx950: FETCH_SIZE reports half of the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM) -> x2; the "
+                       "guide calibrates that for 16-B-per-lane loads, this kernel loads one dword per lane: 2 x FETCH_SIZE here equals "
+                       "the %.1f MB of keys + ~4 MB of status rows the kernel is known to read, so the factor holds for it; both counters "
+                       "sit on the memory side of L2 (fabric requests), Infinity-Cache hits included" % (n * 4 / 1e6),
     "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": 2 * n * 4,
     "how": "two separate runs of `rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py --steps 5 --warmup 1 "
            "--no-cpu-baseline --no-verify` (tools/gpu_session.sh)",
