@@ -49,9 +49,15 @@ struct PendingProf {
 };
 struct Staging {
     void* hptr;
-    size_t bytes;
+    size_t bytes;      // bytes mapped
     hipEvent_t done;   // null while mapped; set at unmap
+    size_t capacity;   // bytes of pinned memory behind hptr (>= bytes when it came from the pool)
 };
+struct PinnedBlock {
+    void* hptr;
+    size_t capacity;
+};
+constexpr size_t kPinnedPoolMax = size_t(512) << 20;   // pinned staging kept for re-use per device handle
 
 }  // namespace
 
@@ -77,8 +83,11 @@ struct adlhip_device {
     std::vector<hipEvent_t> event_pool;
     std::map<std::string, ProfEntry> prof;
     std::vector<std::string> prof_order;
-    // map/unmap staging
+    // map/unmap staging; released staging blocks are pooled: pinning memory costs ~1 ms per 4 MiB, and the
+    // reference's test maps every buffer two or three times (UnitTest/main.cpp:118-139)
     std::vector<Staging> staging;
+    std::vector<PinnedBlock> pinned_pool;
+    size_t pinned_pool_bytes = 0;
     // device-side fault word (look-back timeout etc.), checked at sync
     uint32_t* d_fault = nullptr;
     uint32_t* h_fault = nullptr;   // pinned
@@ -153,7 +162,12 @@ void reap_staging(adlhip_device* d, bool all_done)
         Staging& s = d->staging[i];
         if (s.done && (all_done || hipEventQuery(s.done) == hipSuccess)) {
             hipEventDestroy(s.done);
-            hipHostFree(s.hptr);
+            if (d->pinned_pool_bytes + s.capacity <= kPinnedPoolMax) {
+                d->pinned_pool.push_back({s.hptr, s.capacity});
+                d->pinned_pool_bytes += s.capacity;
+            } else {
+                hipHostFree(s.hptr);
+            }
             d->staging[i] = d->staging.back();
             d->staging.pop_back();
         } else {
@@ -768,6 +782,7 @@ int adlhip_device_destroy(adlhip_device* d)
     hipStreamSynchronize(d->stream);
     reap_staging(d, true);
     for (auto& s : d->staging) hipHostFree(s.hptr);
+    for (auto& b : d->pinned_pool) hipHostFree(b.hptr);
     for (auto& p : d->pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
     for (auto e : d->event_pool) hipEventDestroy(e);
     hipFree(d->d_fault);
@@ -933,13 +948,31 @@ int adlhip_map(adlhip_device* d, void* dptr, size_t bytes, void** hptr)
     reap_staging(d, false);
     if (bytes == 0) return ADLHIP_SUCCESS;
     void* h = nullptr;
-    HIPCHK(hipHostMalloc(&h, bytes));
+    size_t cap = bytes;
+    for (size_t i = 0; i < d->pinned_pool.size(); ++i) {   // smallest pooled block that fits without wasting more than half
+        const PinnedBlock b = d->pinned_pool[i];
+        if (b.capacity >= bytes && b.capacity <= 2 * bytes + 4096 && (!h || b.capacity < cap)) {
+            h = b.hptr;
+            cap = b.capacity;
+        }
+    }
+    if (h) {
+        for (size_t i = 0; i < d->pinned_pool.size(); ++i)
+            if (d->pinned_pool[i].hptr == h) {
+                d->pinned_pool[i] = d->pinned_pool.back();
+                d->pinned_pool.pop_back();
+                break;
+            }
+        d->pinned_pool_bytes -= cap;
+    } else {
+        HIPCHK(hipHostMalloc(&h, bytes));
+    }
     hipError_t e = hipMemcpyAsync(h, dptr, bytes, hipMemcpyDeviceToHost, d->stream);
     if (e != hipSuccess) {
         hipHostFree(h);
         return fail("map: device->host copy failed: %s", hipGetErrorString(e));
     }
-    d->staging.push_back({h, bytes, nullptr});
+    d->staging.push_back({h, bytes, nullptr, cap});
     *hptr = h;
     return ADLHIP_SUCCESS;
 }
