@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -251,24 +253,30 @@ size_t table_bytes(const adlhip_device* d, size_t n, uint32_t tile)
 size_t work_bytes_three_kernel(const adlhip_device* d, size_t n) { return table_bytes(d, n, kMinTile) + 256 * 4; }
 
 // Kernels with more than 64 KiB of dynamic LDS need the limit raised once per function.
+// Kernels that need more than 64 KiB of dynamic LDS must be told so once (per device).  Distinct handles may be driven
+// from distinct host threads, so the bookkeeping is locked.
 template <typename KernelT>
 int ensure_lds(KernelT kernel, size_t bytes)
 {
-    static size_t raised_to = 0;   // one instance per kernel instantiation (KernelT is a distinct fn type only
-                                   // per signature, so key on the pointer as well)
-    static const void* raised_for = nullptr;
     if (bytes <= 64 * 1024) return ADLHIP_SUCCESS;
-    if (raised_for == (const void*)kernel && raised_to >= bytes) return ADLHIP_SUCCESS;
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> raised;   // (kernel, device) -> bytes
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = raised[std::make_pair((const void*)kernel, dev)];
+    if (have >= bytes) return ADLHIP_SUCCESS;
     HIPCHK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    raised_for = (const void*)kernel;
-    raised_to = bytes;
+    have = bytes;
     return ADLHIP_SUCCESS;
 }
 
 // Interned kernel names (the profiler keeps the pointer until the events are folded).
 const char* intern(const std::string& s)
 {
+    static std::mutex mu;
     static std::map<std::string, std::string*> pool;
+    std::lock_guard<std::mutex> lock(mu);
     auto it = pool.find(s);
     if (it == pool.end()) it = pool.emplace(s, new std::string(s)).first;
     return it->second->c_str();
