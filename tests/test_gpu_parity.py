@@ -687,6 +687,43 @@ def test_two_pprims_and_two_devices_do_not_interfere(dev):
 # ---------------------------------------------------------------------------------------------
 # structure-of-arrays key-value sort
 # ---------------------------------------------------------------------------------------------
+def test_two_handles_driven_from_two_host_threads():
+    """include/adlhip.h: distinct handles may be driven from distinct host threads (the reference is single-threaded;
+    the multi-GPU host code is not).  Two threads, each with its own device handle and Pprims, sort different data of
+    sizes that walk through every path (one-workgroup, fused-scan, three-kernel, one-sweep) at the same time."""
+    import threading
+    sizes = [1000, 20000, 70001, 300000, 1 << 20, (1 << 24) + 5, 4097, 1 << 22]
+    errors = []
+
+    def worker(tid):
+        try:
+            d = DeviceUtils.allocate()
+            p = Pprims()
+            try:
+                for rep in range(3):
+                    for n in sizes:
+                        k = oracle.keys_u32(n, seed=1000 * tid + n + rep)
+                        got = gpu_sort_u32(d, p, k)
+                        if not np.array_equal(got, oracle.sort_u32(k)):
+                            errors.append((tid, n, rep, "u32"))
+                        if n <= (1 << 20):
+                            pr = oracle.pairs_kv32(n, seed=7 * tid + n + rep)
+                            if not np.array_equal(gpu_sort_kv(d, p, pr), oracle.sort_kv32(pr)):
+                                errors.append((tid, n, rep, "kv"))
+            finally:
+                p.close()
+                DeviceUtils.deallocate(d)
+        except Exception as e:   # noqa: BLE001 - reported below
+            errors.append((tid, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("algo", [(-1, 8, -1, 1), (0, 8, -1, 1), (1, 8, -1, 1), (0, 4, -1, 0), (1, 4, 0, 1)],
                          ids=["auto8", "onesweep8", "threekernel8", "onesweep4-ballot", "threekernel4-256x16"])
 def test_soa_key_value_sort(dev, pp, algo):
