@@ -9,6 +9,8 @@ from oclradixsort_amd import Buffer, DeviceUtils, Pprims, Stopwatch
 n = (1 << 30) + 12345
 d = DeviceUtils.allocate(); p = Pprims()
 b = Buffer(d, n, np.uint32)
+b.generate(n, seed=98)
+p.radixSort(d, b, n)          # warm-up: the scratch buffers (4 GiB + tables) are allocated here
 b.generate(n, seed=99)
 DeviceUtils.waitForCompletion(d)
 sw = Stopwatch(d); sw.start()
