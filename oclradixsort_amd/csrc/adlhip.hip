@@ -628,9 +628,9 @@ template <typename Buf>
 int run_sort(adlhip_device* d, Buf data, Buf tmp, void* work, size_t n, const std::vector<PassPlan>& plan)
 {
     if (d->sort_algo < 0) {   // automatic choice by size (profiles/r1_ncurve.txt)
-        // the one-sweep path has more fixed cost (histogram, tables) and wins from ~48 MiB of data
-        // (profiles/r1_ncurve.txt: 8Mi u32 keys 104 vs 134 us, 16Mi 196 vs 186 us)
-        if (n * Buf::kElemBytes < (size_t(48) << 20)) return three_kernel_sort<Buf>(d, data, tmp, work, n, plan);
+        // the one-sweep path has more fixed cost (histogram, tables) and wins from ~24 MiB of data (fresh random keys,
+        // profiles/r1_ncurve.txt: 4Mi u32 keys 78 vs 88 us, 8Mi 124 vs 117 us, 16Mi 224 vs 174 us)
+        if (n * Buf::kElemBytes < (size_t(24) << 20)) return three_kernel_sort<Buf>(d, data, tmp, work, n, plan);
     }
     // tile status words carry 30-bit counts: beyond 2^30 elements use the table-based pass
     if (d->sort_algo == 1 || n >= (size_t(1) << 30)) return three_kernel_sort<Buf>(d, data, tmp, work, n, plan);
