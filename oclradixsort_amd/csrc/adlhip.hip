@@ -230,11 +230,14 @@ Geometry geometry(const adlhip_device* d, size_t n, uint32_t tile)
 // "sort.tile" = -1 (default): the measured best per element size on MI355X
 //   4-byte elements: 512 x 32 (16 Ki keys, 73 KiB of LDS, two workgroups per CU)
 //   8-byte elements: 1024 x 16 (16 Ki elements, 145 KiB of LDS, one workgroup per CU)
-//   up to 8 MiB of data: 256 x 16 (4 Ki elements) so that there are enough tiles to occupy 256 CUs
+//   up to 8 MiB of data: 256 x 16 (4 Ki elements) so that there are enough tiles to occupy 256 CUs;
+//   4-byte elements up to 24 MiB: 512 x 16
 int effective_variant(const adlhip_device* d, size_t elem_bytes, size_t n)
 {
     if (d->tile_variant >= 0) return d->tile_variant;
     if (n * elem_bytes <= (size_t(8) << 20)) return 0;
+    // 4-byte keys between 8 and 24 MiB (three-kernel passes): 512 x 16 (8 Ki keys) -- 4Mi keys 75 vs 79 us with 512 x 32
+    if (elem_bytes == 4 && n * elem_bytes < (size_t(24) << 20)) return 1;
     return elem_bytes == 4 ? 6 : 2;
 }
 uint32_t current_tile(const adlhip_device* d, size_t elem_bytes, size_t n)
