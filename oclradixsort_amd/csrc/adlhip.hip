@@ -205,6 +205,7 @@ std::vector<PassPlan> plan_passes(int sort_bits, int digit_bits)
     int sb = 0;
     while (sb < sort_bits) {
         int nb = (digit_bits == 8 && sort_bits - sb >= 8) ? 8 : 4;
+        if (digit_bits == 7 && sort_bits % 7 % 4 == 0 && sort_bits - sb >= 7) nb = 7;   // 7,7,7,7(,4)
         p.push_back({sb, nb});
         sb += nb;
     }
@@ -327,7 +328,7 @@ struct SoaBuf {
 template <typename Buf, int NBITS>
 const char* kernel_name(const char* stem)
 {
-    return intern(std::string(stem) + Buf::tag() + (NBITS == 8 ? "_8b" : "_4b"));
+    return intern(std::string(stem) + Buf::tag() + (NBITS == 8 ? "_8b" : (NBITS == 7 ? "_7b" : "_4b")));
 }
 
 // tile variant: SoA pairs are instantiated for two geometries only (256x16 for small inputs, 1024x16 otherwise)
@@ -346,6 +347,11 @@ uint32_t buf_tile(const adlhip_device* d, size_t n)
 }
 
 #define ADLHIP_DISPATCH_TILE(FN, Buf, NBITS, ...)                                                     \
+    if constexpr (NBITS == 7) {   /* 7-bit digits: the default tiles only */                          \
+        if (Buf::kElemBytes == 4 && !Buf::kSoa)                                                       \
+            return d->rank_mode ? FN<Buf, NBITS, 512, 32, 1>(__VA_ARGS__) : FN<Buf, NBITS, 512, 32, 0>(__VA_ARGS__); \
+        return d->rank_mode ? FN<Buf, NBITS, 1024, 16, 1>(__VA_ARGS__) : FN<Buf, NBITS, 1024, 16, 0>(__VA_ARGS__);   \
+    }                                                                                                 \
     if (Buf::kSoa) {                                                                                  \
         switch (buf_variant<Buf>(d, n) * 2 + (d->rank_mode ? 1 : 0)) {                                \
         case 0: return FN<Buf, NBITS, 256, 16, 0>(__VA_ARGS__);                                       \
@@ -456,7 +462,11 @@ uint32_t hist_wgs_for(const adlhip_device* d, size_t n)
 size_t status_rows(size_t n, uint32_t tile) { return (n + tile - 1) / tile + adlhip::kChains + 1; }
 
 // most passes a sort of `key_bits`-bit keys can need with the current digit width (8,8,8,4 style plans included)
-int max_passes_for(const adlhip_device* d, int key_bits) { return d->digit_bits == 8 ? (key_bits + 7) / 8 : key_bits / 4; }
+int max_passes_for(const adlhip_device* d, int key_bits)
+{
+    if (d->digit_bits == 7) return key_bits / 7 + 1;
+    return d->digit_bits == 8 ? (key_bits + 7) / 8 : key_bits / 4;
+}
 
 OnesweepLayout onesweep_layout(const adlhip_device* d, size_t n, int max_passes, uint32_t tile)
 {
@@ -564,8 +574,10 @@ int onesweep_sort(adlhip_device* d, Buf data, Buf tmp, void* work, size_t n, con
     Buf dst = tmp;
     for (int i = 0; i < P; ++i) {
         uint32_t* st = status + (size_t)i * rows * 256;
-        rc = (plan[i].nbits == 8) ? dispatch_onesweep<Buf, 8>(d, src, dst, tables + i, st, ctrl + i * 16 * adlhip::kTicketStride, n, plan[i].start_bit)
-                                  : dispatch_onesweep<Buf, 4>(d, src, dst, tables + i, st, ctrl + i * 16 * adlhip::kTicketStride, n, plan[i].start_bit);
+        uint32_t* tk = ctrl + i * 16 * adlhip::kTicketStride;
+        rc = (plan[i].nbits == 8)   ? dispatch_onesweep<Buf, 8>(d, src, dst, tables + i, st, tk, n, plan[i].start_bit)
+             : (plan[i].nbits == 7) ? dispatch_onesweep<Buf, 7>(d, src, dst, tables + i, st, tk, n, plan[i].start_bit)
+                                    : dispatch_onesweep<Buf, 4>(d, src, dst, tables + i, st, tk, n, plan[i].start_bit);
         if (rc) return rc;
         std::swap(src, dst);
     }
@@ -630,13 +642,15 @@ size_t sort_work_bytes(const adlhip_device* d, int elem_kind, size_t n)
 template <typename Buf>
 int run_sort(adlhip_device* d, Buf data, Buf tmp, void* work, size_t n, const std::vector<PassPlan>& plan)
 {
-    if (d->sort_algo < 0) {   // automatic choice by size (profiles/r1_ncurve.txt)
+    const bool seven = !plan.empty() && plan[0].nbits == 7;   // 7-bit digits exist in the one-sweep pass only
+    if (d->sort_algo < 0 && !seven) {   // automatic choice by size (profiles/r1_ncurve.txt)
         // the one-sweep path has more fixed cost (histogram, tables) and wins from ~24 MiB of data (fresh random keys,
         // profiles/r1_ncurve.txt: 4Mi u32 keys 78 vs 88 us, 8Mi 124 vs 117 us, 16Mi 224 vs 174 us)
         if (n * Buf::kElemBytes < (size_t(24) << 20)) return three_kernel_sort<Buf>(d, data, tmp, work, n, plan);
     }
     // tile status words carry 30-bit counts: beyond 2^30 elements use the table-based pass
-    if (d->sort_algo == 1 || n >= (size_t(1) << 30)) return three_kernel_sort<Buf>(d, data, tmp, work, n, plan);
+    if (seven && n >= (size_t(1) << 30)) return fail("sort.digit_bits = 7 supports fewer than 2^30 elements");
+    if (!seven && (d->sort_algo == 1 || n >= (size_t(1) << 30))) return three_kernel_sort<Buf>(d, data, tmp, work, n, plan);
     return onesweep_sort<Buf>(d, data, tmp, work, n, plan);
 }
 
@@ -773,7 +787,7 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
     if (const char* a = getenv("ADLHIP_SORT_ALGO")) { int v = atoi(a); if (v >= -1 && v <= 1) d->sort_algo = v; }
     if (const char* t = getenv("ADLHIP_SORT_TILE")) { int v = atoi(t); if (v >= -1 && v < kNumVariants) d->tile_variant = v; }
     if (const char* r = getenv("ADLHIP_SORT_RANK")) d->rank_mode = (atoi(r) && d->lds_ordered) ? 1 : 0;
-    if (const char* b = getenv("ADLHIP_DIGIT_BITS")) d->digit_bits = (atoi(b) == 4) ? 4 : 8;
+    if (const char* b = getenv("ADLHIP_DIGIT_BITS")) { int v = atoi(b); d->digit_bits = (v == 4 || v == 7) ? v : 8; }
     *out = d;
     return ADLHIP_SUCCESS;
 }
@@ -1138,7 +1152,7 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
         if (value < -1 || value > 1) return fail("sort.algo must be -1, 0 or 1");
         d->sort_algo = value;
     } else if (!strcmp(name, "sort.digit_bits")) {
-        if (value != 4 && value != 8) return fail("sort.digit_bits must be 4 or 8");
+        if (value != 4 && value != 7 && value != 8) return fail("sort.digit_bits must be 4, 7 or 8");
         d->digit_bits = value;
     } else if (!strcmp(name, "sort.tile")) {
         if (value < -1 || value >= kNumVariants) return fail("sort.tile must be in [-1,%d)", kNumVariants);

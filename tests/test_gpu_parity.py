@@ -382,15 +382,82 @@ def test_full_size_64m_key_value(dev, pp):
 
 
 def test_full_size_256m_u64(dev, pp):
+    """BASELINE config #5 at its stated size, bit-exact against the oracle (2 GiB of keys)."""
     n = 1 << 28
     keys = oracle.keys_u64(n, seed=123)
     got = gpu_sort_u64(dev, pp, keys)
     assert np.all(got[1:] >= got[:-1])
     assert _checksums(got) == _checksums(keys)
+    want = oracle.sort_u64(keys)
     del keys
+    assert np.array_equal(got, want)
+    del want
     # a second, independent run must give the identical array (determinism)
     again = gpu_sort_u64(dev, pp, oracle.keys_u64(n, seed=123))
     assert np.array_equal(got, again)
+
+
+# ---------------------------------------------------------------------------------------------
+# the size classes BASELINE config #4 runs on every GPU: u32 one-sweep beyond 256 MiB of keys (the write-out leaves
+# the raw-buffer stores for 64-bit pointer stores, radix_kernels.hpp dst_fits32 / write_out_tile) and the
+# n >= 2^30 three-kernel path (30-bit status counts no longer suffice).  Contract: Pprims.cpp:304-406.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [(1 << 26) + 12345, 1 << 27, 1 << 28], ids=["64Mi+12345", "128Mi", "256Mi"])
+def test_u32_onesweep_beyond_256_mib(dev, pp, n):
+    set_algo(dev, (0, 8, -1))
+    keys = oracle.keys_u32(n, seed=n & 0xffff)
+    got = gpu_sort_u32(dev, pp, keys)
+    assert np.array_equal(got, oracle.sort_u32(keys))
+
+
+@pytest.mark.parametrize("n", [(1 << 25) + 4321, (1 << 26) + 12345, 1 << 27], ids=["32Mi+4321", "64Mi+12345", "128Mi"])
+def test_kv32_onesweep_beyond_256_mib(dev, pp, n):
+    """{key, value} pairs past the buffer-store limit (8-byte elements: 32 Mi pairs), 20-bit keys so that stability is
+    exercised by ~128 duplicates per key."""
+    set_algo(dev, (0, 8, -1))
+    pairs = oracle.pairs_kv32(n, seed=n & 0xfff) & np.uint64(0xffffffff000fffff)
+    got = gpu_sort_kv(dev, pp, pairs)
+    assert np.array_equal(got, oracle.sort_kv32(pairs))
+
+
+def test_soa_64m_pairs(dev, pp):
+    """SoA key/value sort at BASELINE config #3's size."""
+    n = 1 << 26
+    keys = oracle.keys_u32(n, seed=77) & np.uint32(0x00ffffff)     # 24-bit keys: duplicates
+    vals = np.arange(n, dtype=np.uint32)
+    kb, vb = Buffer(dev, n, np.uint32), Buffer(dev, n, np.uint32)
+    kb.write(keys); vb.write(vals)
+    pp.radixSortSoA(dev, kb, vb, n, 32)
+    gk, gv = kb.toHost(), vb.toHost()
+    kb.release(); vb.release()
+    want = oracle.sort_kv32(keys.astype(np.uint64) | (vals.astype(np.uint64) << np.uint64(32)))
+    assert np.array_equal(gk, (want & np.uint64(0xffffffff)).astype(np.uint32))
+    assert np.array_equal(gv, (want >> np.uint64(32)).astype(np.uint32))
+
+
+def test_u32_2p30_plus_12345_three_kernel_path(dev, pp):
+    """n >= 2^30: the automatic choice must leave the one-sweep path (status words carry 30-bit counts); 4 GiB of keys,
+    element indices close to the 32-bit limit of the kernels.  Bit-exact against the oracle."""
+    n = (1 << 30) + 12345
+    keys = oracle.keys_u32(n, seed=99)
+    b = Buffer(dev, n, np.uint32)
+    b.write(keys)
+    dev.toggleProfiling(True)
+    dev.profile(reset=True)
+    pp.radixSort(dev, b, n)
+    prof = dev.profile(reset=True)
+    dev.toggleProfiling(False)
+    assert any(k.startswith("scatter_u32") for k in prof) and not any(k.startswith("onesweep") for k in prof), prof
+    want = oracle.sort_u32(keys)
+    del keys
+    CH = 1 << 27
+    chunk = np.empty(CH, dtype=np.uint32)
+    for off in range(0, n, CH):
+        m = min(CH, n - off)
+        b.read(chunk[:m], m, off)
+        DeviceUtils.waitForCompletion(dev)
+        assert np.array_equal(chunk[:m], want[off:off + m]), off
+    b.release()
 
 
 def test_stopwatch_and_profiling(dev, pp):
