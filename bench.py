@@ -7,11 +7,12 @@
 A "step" is one complete radix sort of one batch of synthetic keys that is already resident in HBM:
   N = 1 : BASELINE config #2, key-only RadixSort32, 64Mi uniform-random u32 keys, in place
           (Pprims::radixSort path: adlhip_radix_sort_u32).
-  N > 1 : every rank holds 64Mi keys (weak scaling); a step = MSB-bucket partition -> RCCL all-to-all
-          -> local sort (oclradixsort_amd/dist.py).  The K steps are independent batches fed through
-          ShardedRadixSort.sort_stream: the exchange of batch i+1 (xGMI-bound) overlaps the local sort of
-          batch i (HBM-bound); the un-pipelined per-step time and stage breakdown are reported under
-          "serial" beside the metric.
+  N > 1 : every rank holds 64Mi keys (weak scaling); a step = top-byte partition -> balanced splitters from the
+          all-reduced histogram -> RCCL all-to-all -> local sort (oclradixsort_amd/dist.py).  The K steps are
+          independent batches fed through ShardedRadixSort.sort_stream: the exchange of batch i+1 (xGMI-bound)
+          overlaps the local sort of batch i (HBM-bound); the un-pipelined per-step time and stage breakdown are
+          reported under "serial" beside the metric.  Beside it, under "config4", BASELINE config #4 at its stated
+          size: 2^30 keys in total, 2^30 / N per GPU (2^27 at N = 8), a few steps through the same pipeline.
 Every step sorts its OWN pre-generated random buffer (K + W buffers of 256 MiB are generated on the
 device before the timed region), so no step sees pre-sorted data and no restore copy is timed.
 
@@ -37,7 +38,7 @@ sys.path.insert(0, ROOT)
 N_KEYS = 1 << 26            # 64Mi keys per GPU
 ELEM_BYTES = 4
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
-ALGO_BYTES_PER_KEY_SORT = 96.0   # 8 four-bit passes x 3 x 4 B (the reference's pass count)
+CONFIG4_TOTAL_KEYS = 1 << 30     # BASELINE config #4: 1B u32 keys over the GPUs of one node
 
 
 def cpu_baseline(n):
@@ -254,6 +255,12 @@ def main():
         out["device"] = info_name
         out["verified_vs_oracle"] = verified
         out["event_ms_per_step"] = ev_ms / K
+        # whole sort on the bytes it really moves: one histogram read + (read + write) per global pass
+        passes = max(1, round(sum(v[0] for k, v in prof.items() if k.startswith(("onesweep_", "scatter_", "segment_sort"))) / K))
+        moved = ELEM_BYTES * (1 + 2 * passes)
+        out["whole_sort"] = {"global_passes": passes, "bytes_moved_per_key": moved,
+                             "achieved_GBps": n * moved / (ev_ms / K * 1e-3) / 1e9,
+                             "frac_of_peak": n * moved / (ev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS}
         parallelism = "1 GPU"
         workload = "Key-only RadixSort32, %d uniform-random u32 keys (splitmix64 hi32, seed 123+step), 1xMI355X, in place" % n
         algo_name = {0: "onesweep", 1: "three-kernel", -1: "auto (one-sweep at this size)"}.get(algo, str(algo))
@@ -267,31 +274,64 @@ def main():
             be.setParam("sort.digit_bits", args.digit_bits)
         # ADLHIP_BENCH_FORCE_BUCKETS=8 with ADLHIP_BENCH_FORCE_DIST=1: pay an 8-rank partition pass on the 1-GPU rehearsal
         sorter = ShardedRadixSort(be, rehearse_buckets=int(os.environ.get("ADLHIP_BENCH_FORCE_BUCKETS", "0")) if force_dist else 0)
-        inputs = []
-        for i in range(K + W):
-            t = be.empty(n)
-            b = Buffer(dtype=np.uint32)
-            b.setRawPtr(be.device, t.data_ptr(), n)
-            # global index space: rank r owns indices [r*n, (r+1)*n) of step i's key sequence
-            b.generate(n, seed=123 + i, firstIndex=rank * n)
-            inputs.append(t)
-        be.reserve(n)   # slots and scratch of the pipeline: allocated before anything is timed, whatever W is
-        torch.cuda.synchronize()
+
+        def make_inputs(nk, count, seed0):
+            ts = []
+            for i in range(count):
+                t = be.empty(nk)
+                b = Buffer(dtype=np.uint32)
+                b.setRawPtr(be.device, t.data_ptr(), nk)
+                # global index space: rank r owns indices [r*nk, (r+1)*nk) of step i's key sequence
+                b.generate(nk, seed=seed0 + i, firstIndex=rank * nk)
+                ts.append(t)
+            return ts
 
         def run(batches):
-            # the K independent batches go through the two-stage pipeline (dist.py: batch i+1's partition +
+            # the independent batches go through the two-stage pipeline (dist.py: batch i+1's partition +
             # all-to-all overlap batch i's local sort); fill and drain of the pipeline are inside the timed region
             last = None
             for last in sorter.sort_stream(batches, force_exchange=force_dist):
                 pass
             return last
 
+        def verify(res, nk, seed_last):
+            """Size-independent checks on the last batch: local sortedness, ownership (this rank's top bytes lie inside
+            its splitter range, or equal its fixed bucket), global count and checksum conservation."""
+            x = res.view(torch.int32) ^ (-2147483648)           # order-preserving u32 -> i32 map
+            ok = bool((x[1:] >= x[:-1]).all().item()) if x.numel() > 1 else True
+            top = (res.to(torch.int64) & 0xffffffff) >> 24
+            if sorter.last_bounds is not None and res.numel():
+                # sort_stream has already partitioned nothing newer than the last batch: these are its bounds
+                b = sorter.last_bounds
+                ok = ok and bool(((top >= b[rank]) & (top < b[rank + 1])).all().item())
+            elif res.numel():
+                ok = ok and bool(((top >> (8 - (world.bit_length() - 1))) == rank).all().item())
+            cnt = torch.tensor([res.numel(), int((res.to(torch.int64) & 0xffffffff).sum().item())],
+                               dtype=torch.int64, device=res.device)
+            dist.all_reduce(cnt)
+            ref_t = make_inputs(nk, 1, seed_last)[0]
+            torch.cuda.synchronize()
+            ref_cnt = torch.tensor([nk, int((ref_t.to(torch.int64) & 0xffffffff).sum().item())],
+                                   dtype=torch.int64, device=res.device)
+            dist.all_reduce(ref_cnt)
+            ok = ok and bool((cnt == ref_cnt).all().item())
+            flag = torch.tensor([1 if ok else 0], device=res.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+
+        inputs = make_inputs(n, K + W, 123)
+        be.reserve(n)   # slots and scratch of the pipeline: allocated before anything is timed, whatever W is
+        torch.cuda.synchronize()
         res = run(inputs[:W])
         barrier()
         t0 = time.perf_counter()
         res = run(inputs[W:W + K])
         barrier()
         wall = time.perf_counter() - t0
+        share = torch.tensor([res.numel()], dtype=torch.int64, device=res.device)
+        if dist.is_initialized():
+            dist.all_reduce(share, op=dist.ReduceOp.MAX)
+        out["max_rank_share_over_mean"] = float(share.item()) / float(n)
 
         # for the record, not the metric: the same K batches one at a time (partition -> all-gather -> all-to-all ->
         # local sort back to back on one stream), with a per-stage breakdown from events on this rank
@@ -311,7 +351,7 @@ def main():
         out["serial"] = {
             "ms_per_step": serial_wall / K * 1e3,
             "Gkeys_per_s": float(n) * world * K / serial_wall / 1e9,
-            "rank0_stage_ms": {"partition": st[0] / K, "count_allgather_and_host_sync": st[1] / K,
+            "rank0_stage_ms": {"partition_and_splitters": st[0] / K, "count_allgather_and_host_sync": st[1] / K,
                                "all_to_all": st[2] / K, "local_sort": st[3] / K},
             # bytes this rank put on the links per step (everything but its own bucket) / the all-to-all's duration
             "rank0_all_to_all_out_GBps": (sum(sorter.last_splits[0]) - sorter.last_splits[0][rank]) * 4.0 / max(st[2] / K * 1e-3, 1e-12) / 1e9,
@@ -319,35 +359,54 @@ def main():
         }
         verified = None
         if not args.no_verify:
-            # size-independent checks on the last batch: local sortedness, bucket ownership, global
-            # count and checksum conservation (inputs regenerated for the checksum)
-            x = res.view(torch.int32) ^ (-2147483648)           # order-preserving u32 -> i32 map
-            ok = bool((x[1:] >= x[:-1]).all().item()) if x.numel() > 1 else True
-            shift = 32 - (world.bit_length() - 1)
-            top = (res.to(torch.int64) & 0xffffffff) >> shift
-            ok = ok and bool((top == rank).all().item())
-            cnt = torch.tensor([res.numel(), int((res.to(torch.int64) & 0xffffffff).sum().item())],
-                               dtype=torch.int64, device=res.device)
-            dist.all_reduce(cnt)
-            ref_t = be.empty(n)
-            rb = Buffer(dtype=np.uint32)
-            rb.setRawPtr(be.device, ref_t.data_ptr(), n)
-            rb.generate(n, seed=123 + W + K - 1, firstIndex=rank * n)
-            torch.cuda.synchronize()
-            ref_cnt = torch.tensor([n, int((ref_t.to(torch.int64) & 0xffffffff).sum().item())],
-                                   dtype=torch.int64, device=res.device)
-            dist.all_reduce(ref_cnt)
-            ok = ok and bool((cnt == ref_cnt).all().item())
-            flag = torch.tensor([1 if ok else 0], device=res.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            verified = bool(flag.item())
+            res = run(inputs[W + K - 1:W + K])      # bounds and result of the same (last) batch
+            verified = verify(res, n, 123 + W + K - 1)
             if not verified:
                 raise SystemExit("bench: multi-GPU result failed sortedness/ownership/checksum checks")
         out["verified_properties"] = verified
         del inputs, res
+
+        # BASELINE config #4 at its stated size, beside the weak-scaling metric: 2^30 keys in total over the ranks
+        # (2^27 per GPU at N = 8).  A few steps through the same pipeline; not the line's `value`.
+        if os.environ.get("ADLHIP_BENCH_CONFIG4", "1") != "0" and (world > 1 or os.environ.get("ADLHIP_BENCH_CONFIG4") == "1"):
+            try:
+                n4 = int(os.environ.get("ADLHIP_BENCH_CONFIG4_TOTAL", CONFIG4_TOTAL_KEYS)) // world
+                K4, W4 = 3, 1
+                torch.cuda.empty_cache()
+                in4 = make_inputs(n4, K4 + W4, 900)
+                be.reserve(n4)
+                torch.cuda.synchronize()
+                r4 = run(in4[:W4])
+                barrier()
+                t4 = time.perf_counter()
+                r4 = run(in4[W4:])
+                barrier()
+                w4 = time.perf_counter() - t4
+                if dist.is_initialized():
+                    tt = torch.tensor([w4], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    w4 = float(tt.item())
+                v4 = None
+                if not args.no_verify:
+                    r4 = run(in4[-1:])
+                    v4 = verify(r4, n4, 900 + K4 + W4 - 1)
+                    if not v4:
+                        raise RuntimeError("config #4 result failed sortedness/ownership/checksum checks")
+                out["config4"] = {
+                    "workload": "BASELINE config #4: %d u32 keys sharded across %d x MI355X (%d per GPU), top-byte partition + balanced "
+                                "splitters + RCCL all-to-all + local RadixSort32" % (n4 * world, world, n4),
+                    "keys_per_gpu": n4, "total_keys": n4 * world, "steps": K4, "warmup": W4,
+                    "ms_per_step": w4 / K4 * 1e3, "Gkeys_per_s": float(n4) * world * K4 / w4 / 1e9,
+                    "scaling": "strong (total fixed at 2^30 keys)", "verified_properties": v4,
+                }
+                del in4, r4
+            except Exception as e:   # never lose the metric line to the side measurement
+                out["config4"] = {"error": repr(e)[:300]}
         be.close()
-        parallelism = "msb-bucket x%d (all-to-all over RCCL), exchange of batch i+1 overlapped with local sort of batch i" % world
-        workload = "%d uniform-random u32 keys per GPU (weak scaling), MSB-bucket partition + all-to-all + local RadixSort32" % n
+        parallelism = ("top-byte buckets with balanced splitters x%d (all-to-all over RCCL), exchange of batch i+1 overlapped "
+                       "with local sort of batch i" % world)
+        workload = ("%d uniform-random u32 keys per GPU (weak scaling), top-byte partition + balanced splitters + all-to-all + "
+                    "local RadixSort32" % n)
         cfg_extra = {}
 
     # max over ranks
@@ -373,8 +432,6 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": dict({"workload": workload, "keys_per_gpu": n, "parallelism": parallelism}, **cfg_extra),
-            # whole-sort fraction under BASELINE.md's definition (96 algorithmic bytes per key per sort)
-            "sort_roofline_frac_96B_per_key": (value / world) * ALGO_BYTES_PER_KEY_SORT / HBM_PEAK_GBS,
         }
         line.update(out)
         if rehearse:

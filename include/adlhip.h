@@ -71,6 +71,15 @@ uint64_t adlhip_used_bytes(adlhip_device* dev);
  * Also reports, as a failure, any device-side fault flag a kernel raised since the last sync. */
 int adlhip_sync(adlhip_device* dev);
 
+/* Stream-ordered fault check that never blocks, for callers that drain the stream by other means (a handle
+ * made with adlhip_device_create_on_stream and synchronised through the stream's owner, e.g. torch): enqueues a
+ * copy of the device's sticky fault word into pinned memory and reports -- as a failure, clearing the word -- what
+ * the PREVIOUS such copy delivered once it has completed.  Call it once per batch: a look-back time-out or an
+ * oversized segment of batch i surfaces at the check that follows the completion of batch i.  The live word the
+ * waiters poll is cleared by the first kernel of every sort, so a failure never leaks into later sorts.
+ * No reference counterpart (its errors are ADLASSERTs on the host, Tahoe/Math/Error.h:24-38). */
+int adlhip_fault_check(adlhip_device* dev);
+
 /* DeviceUtils::flush -- Adl/CL/AdlCL.inl:614-617.  HIP streams need no flush; kept for symmetry. */
 int adlhip_flush(adlhip_device* dev);
 
@@ -122,7 +131,11 @@ int adlhip_unmap(adlhip_device* dev, void* dptr, void* hptr, size_t bytes);
 /* Scratch the caller must own, replacing Pprims' m_u32WorkBuffer[0] (ping-pong copy of the data,
  * Pprims.cpp:226-232, :332) and m_u32WorkBuffer[1] (histogram table, :229-230, :333-337).
  *   *tmp_bytes  : second data buffer, n elements
- *   *work_bytes : control scratch (digit tables / tile status words), depends on n and the device */
+ *   *work_bytes : control scratch (digit tables / tile status words), depends on n and the device.  The value
+ *                 suffices for EVERY n' <= n with the current knobs (the need of a single n is not monotone:
+ *                 smaller inputs use smaller tiles and so more status rows), so a caller may size its scratch
+ *                 once for its largest batch; changing "sort.tile", "sort.digit_bits" or "sort.algo" later can
+ *                 raise the requirement (the sort entry points re-check and fail loudly). */
 int adlhip_radix_sort_scratch_bytes(adlhip_device* dev, int elem_kind, size_t n,
                                     size_t* tmp_bytes, size_t* work_bytes);
 
@@ -154,6 +167,20 @@ int adlhip_radix_sort_soa32(adlhip_device* dev, uint32_t* d_keys_inout, uint32_t
 int adlhip_radix_sort_u64(adlhip_device* dev, uint64_t* d_keys_inout, uint64_t* d_tmp,
                           void* d_work, size_t work_bytes, size_t n, int sort_bits);
 
+/* ---- segments finished in LDS (no reference counterpart) ------------------------------------- */
+
+/* Sorts, stably and in place, every segment [d_seg_start[s], d_seg_start[s + 1]) of an array of u32 keys
+ * (ADLHIP_ELEM_U32) or {key, value} pairs (ADLHIP_ELEM_KV32) by the low `low_bits` bits of its keys: one
+ * workgroup per segment, the segment lives in LDS, one read and one write of global memory.  It is the
+ * finishing pass of the hybrid sort ("sort.algo" = 2: two MSD passes of the kind
+ * Tahoe/ClKernels/RadixSort32Kernels.cl:493-631 implements per digit, then this) and usable on its own.
+ * d_seg_start: num_segments + 1 ascending element offsets in device memory.  max_segment: the caller's bound
+ * on the largest segment (selects the LDS tile): at most 16384 keys / 8192 pairs for low_bits <= 24, half of
+ * that up to 27 bits.  A segment that exceeds the tile is left unsorted and raises the device fault word
+ * (reported by adlhip_sync / adlhip_fault_check). */
+int adlhip_segment_sort(adlhip_device* dev, int elem_kind, void* d_data, const uint32_t* d_seg_start,
+                        size_t num_segments, size_t max_segment, int low_bits);
+
 /* Pprims::scan(const Device*, Buffer<int>& dst, const Buffer<int>& src, int n, u32* sumOut=0)
  * -- Pprims.h:35, Pprims.cpp:122-179.  Exclusive prefix sum, 32-bit wrap-around.  dst may equal src.
  * h_sum_or_null: when non-NULL the grand total is copied there (stream-ordered; valid after
@@ -177,6 +204,50 @@ int adlhip_partition_msb_kv32(adlhip_device* dev, const void* d_pairs_in, void* 
                               uint32_t* d_counts_out, void* d_work, size_t work_bytes,
                               size_t n, int num_buckets);
 
+/* The same pass with the 256 top-byte totals handed out instead of folded: out = in, stably ordered by the key's
+ * bits 24..31; d_totals256_out[b] (u32) = number of keys whose top byte is b.  The sharded sort all-reduces these
+ * totals over the ranks and cuts the byte range into G contiguous pieces of near-equal population (balanced
+ * splitters); any such cut yields G contiguous send segments of this output. */
+int adlhip_partition_top_byte_u32(adlhip_device* dev, const uint32_t* d_keys_in, uint32_t* d_keys_out,
+                                  uint32_t* d_totals256_out, void* d_work, size_t work_bytes, size_t n);
+int adlhip_partition_top_byte_kv32(adlhip_device* dev, const void* d_pairs_in, void* d_pairs_out,
+                                   uint32_t* d_totals256_out, void* d_work, size_t work_bytes, size_t n);
+
+/* ---- sharded sort: ONE process, G devices (no reference counterpart) ------------------------
+ *
+ * The reference's API language is C++ (Tahoe/ParallelPrimitives/Pprims.h:35-41) and it drives one device
+ * (Adl/Adl.h:90-94).  A group owns one adlhip_device per GPU and one RCCL communicator per device
+ * (ncclCommInitAll; RCCL is loaded with dlopen on first use).  adlhip_sharded_sort_* sorts G shards that live
+ * on the G devices into ONE global order: rank r ends up with a contiguous, ascending slice and the slices in
+ * rank order are the sorted whole (pairs: stable in (source rank, position) order).  Steps: stable partition by
+ * the top byte on every device (adlhip_partition_top_byte_*), ONE host synchronisation that brings the G x 256
+ * totals to the host, balanced splitters (contiguous top-byte ranges of near-equal population; a rank's share
+ * exceeds the mean by at most one byte value's population), one grouped ncclSend/ncclRecv exchange (every pair
+ * of GPUs of a node has its own xGMI link), local sort.  The call returns with the exchange and the local sorts
+ * ENQUEUED on the devices' streams: results are valid after adlhip_sync() on each device of the group.
+ * Like every handle, a group must be driven by one host thread at a time. */
+typedef struct adlhip_group adlhip_group;
+
+/* device_indices: num_devices distinct HIP device indices, or NULL for 0 .. num_devices-1. */
+int adlhip_group_create(const int* device_indices, int num_devices, adlhip_group** out);
+/* Frees the group's scratch, communicators and device handles.  Fails (like adlhip_device_destroy,
+ * Adl/Adl.inl:100-105) while the caller still holds memory allocated from one of its devices. */
+int adlhip_group_destroy(adlhip_group* group);
+int adlhip_group_size(adlhip_group* group);
+/* The handle of rank `rank` (allocate the shards and outputs with it; NULL if out of range). */
+adlhip_device* adlhip_group_device(adlhip_group* group, int rank);
+/* Top-byte boundaries of the last sharded sort: bounds_out[G + 1], rank r owns top bytes [b[r], b[r+1]). */
+int adlhip_group_last_bounds(adlhip_group* group, int* bounds_out);
+
+/* d_shards_in[r]: n_in[r] keys on device r (left intact).  d_out[r]: room for out_capacity[r] keys on device r;
+ * n_out[r] receives the size of rank r's slice.  If a slice does not fit, the call fails before anything is
+ * exchanged and n_out holds the required sizes (1.25 x the mean + slack is enough unless one byte value dominates). */
+int adlhip_sharded_sort_u32(adlhip_group* group, uint32_t* const* d_shards_in, const size_t* n_in,
+                            uint32_t* const* d_out, const size_t* out_capacity, size_t* n_out);
+/* Same for {u32 key, u32 value} pairs (8-byte elements, key in the low dword; Pprims.h:38). */
+int adlhip_sharded_sort_kv32(adlhip_group* group, void* const* d_shards_in, const size_t* n_in,
+                             void* const* d_out, const size_t* out_capacity, size_t* n_out);
+
 /* ---- synthetic inputs: generated in place, reproducible by index ---------- */
 
 /* key32(i) = hi32(splitmix64(seed*0x9E3779B97F4A7C15 + first_index + i)); key64 = the full 64 bits;
@@ -189,7 +260,7 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
 
 /* Integer tunables, by name.  Unknown names fail.  Current names:
  *   "sort.algo"        -1 [default] = by size: n <= 16384 one workgroup does the whole sort in one launch;
- *                      below ~96 MiB of data the three-kernel pass; above it the one-sweep path
+ *                      below 24 MiB of data the three-kernel pass; from there on the one-sweep path
  *                      0 = onesweep (one sweep per digit, 16 decoupled look-back chains)
  *                      1 = three kernels per pass: count -> table scan -> sort+scatter (the
  *                          reference's pass structure, Pprims.cpp:357-398)
@@ -229,6 +300,13 @@ int adlhip_profile_write_csv(adlhip_device* dev, const char* path);
 /* ---- bandwidth probes (diagnostics for bench.py: empirical HBM ceilings) ---------------------- */
 int adlhip_probe_copy(adlhip_device* dev, void* d_dst, const void* d_src, size_t bytes);
 int adlhip_probe_read(adlhip_device* dev, const void* d_src, size_t bytes, void* d_sink8);
+
+/* Re-runs the device self-test that "sort.rank" = 1 rests on (returning DS atomics of one wave instruction
+ * resolve colliding lanes in ascending lane order; ranks are compared with ballot/mbcnt ranks) with `workgroups`
+ * workgroups of 256 and of 1024 threads, and BLOCKS until the number of disagreements is in *mismatches
+ * (0 = the property holds).  Device creation runs it once on an idle chip; stress tests call it on a second
+ * handle while sorts run on the first.  No reference counterpart. */
+int adlhip_selftest_lds_order(adlhip_device* dev, int workgroups, uint32_t* mismatches);
 
 const char* adlhip_version(void);
 

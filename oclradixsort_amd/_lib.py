@@ -42,6 +42,7 @@ SIGNATURES = {
     "adlhip_device_info": (_I, [_VP, ctypes.POINTER(Info)]),
     "adlhip_used_bytes": (ctypes.c_uint64, [_VP]),
     "adlhip_sync": (_I, [_VP]),
+    "adlhip_fault_check": (_I, [_VP]),
     "adlhip_flush": (_I, [_VP]),
     "adlhip_stream": (_VP, [_VP]),
     "adlhip_last_error": (ctypes.c_char_p, []),
@@ -60,10 +61,20 @@ SIGNATURES = {
     "adlhip_radix_sort_kv32": (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
     "adlhip_radix_sort_soa32": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
     "adlhip_radix_sort_u64": (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
+    "adlhip_segment_sort": (_I, [_VP, _I, _VP, _VP, _SZ, _SZ, _I]),
     "adlhip_scan_scratch_bytes": (_I, [_VP, _SZ, c_size_p]),
     "adlhip_exclusive_scan_u32": (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _VP]),
     "adlhip_partition_msb_u32": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
     "adlhip_partition_msb_kv32": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
+    "adlhip_partition_top_byte_u32": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ]),
+    "adlhip_partition_top_byte_kv32": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ]),
+    "adlhip_group_create": (_I, [ctypes.POINTER(_I), _I, c_void_pp]),
+    "adlhip_group_destroy": (_I, [_VP]),
+    "adlhip_group_size": (_I, [_VP]),
+    "adlhip_group_device": (_VP, [_VP, _I]),
+    "adlhip_group_last_bounds": (_I, [_VP, ctypes.POINTER(_I)]),
+    "adlhip_sharded_sort_u32": (_I, [_VP, c_void_pp, c_size_p, c_void_pp, c_size_p, c_size_p]),
+    "adlhip_sharded_sort_kv32": (_I, [_VP, c_void_pp, c_size_p, c_void_pp, c_size_p, c_size_p]),
     "adlhip_generate_keys": (_I, [_VP, _I, _VP, _SZ, ctypes.c_uint64, ctypes.c_uint64]),
     "adlhip_set_param": (_I, [_VP, ctypes.c_char_p, _I]),
     "adlhip_get_param": (_I, [_VP, ctypes.c_char_p, ctypes.POINTER(_I)]),
@@ -78,6 +89,7 @@ SIGNATURES = {
     "adlhip_profile_write_csv": (_I, [_VP, ctypes.c_char_p]),
     "adlhip_probe_copy": (_I, [_VP, _VP, _VP, _SZ]),
     "adlhip_probe_read": (_I, [_VP, _VP, _SZ, _VP]),
+    "adlhip_selftest_lds_order": (_I, [_VP, _I, ctypes.POINTER(ctypes.c_uint32)]),
     "adlhip_version": (ctypes.c_char_p, []),
 }
 

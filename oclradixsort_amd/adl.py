@@ -92,6 +92,11 @@ class Device:
         """Append the per-kernel timing table as CSV (the reference's ProfileCL.*.csv hook)."""
         check(_lib.load().adlhip_profile_write_csv(self._h, path.encode()), "adlhip_profile_write_csv")
 
+    def checkFault(self):
+        """Non-blocking, stream-ordered fault check (adlhip_fault_check) for handles whose stream is synchronised by
+        someone else (torch): raises for a device-side fault of an EARLIER, completed batch."""
+        check(_lib.load().adlhip_fault_check(self._h), "adlhip_fault_check")
+
     @property
     def stream(self):
         return _lib.load().adlhip_stream(self._h)
@@ -127,7 +132,10 @@ class DeviceUtils:
 
     @staticmethod
     def waitForCompletion(device):
-        check(_lib.load().adlhip_sync(device._h), "adlhip_sync")
+        try:
+            check(_lib.load().adlhip_sync(device._h), "adlhip_sync")
+        finally:
+            device.__dict__.pop("_staged", None)     # host arrays staged by Buffer.write are no longer needed
 
     @staticmethod
     def flush(device):
@@ -205,7 +213,10 @@ class Buffer:
         a = np.ascontiguousarray(hostSrc, dtype=self.dtype)
         n = a.size if nElems is None else int(nElems)
         assert dstOffsetNElems + n <= self.m_size
-        self._keep = a   # keep the host memory alive until the caller syncs
+        # keep every staged host array alive until the caller syncs (a second write before the sync must not drop
+        # the first one's source while its copy may still be pending)
+        keep = self.m_device.__dict__.setdefault("_staged", [])
+        keep.append(a)
         check(_lib.load().adlhip_memcpy_h2d(self.m_device._h, self.ptr(dstOffsetNElems),
                                             a.ctypes.data_as(ctypes.c_void_p), n * self.dtype.itemsize), "h2d")
 

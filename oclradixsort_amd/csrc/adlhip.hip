@@ -19,6 +19,7 @@
 
 #include "radix_kernels.hpp"
 #include "onesweep_kernels.hpp"
+#include "hybrid_kernels.hpp"
 
 namespace {
 
@@ -90,9 +91,11 @@ struct adlhip_device {
     std::vector<Staging> staging;
     std::vector<PinnedBlock> pinned_pool;
     size_t pinned_pool_bytes = 0;
-    // device-side fault word (look-back timeout etc.), checked at sync
+    // device-side fault words ([0] live, [1] sticky: onesweep_kernels.hpp raise_fault), checked at sync and by
+    // adlhip_fault_check; [8] is the self-test's result slot
     uint32_t* d_fault = nullptr;
-    uint32_t* h_fault = nullptr;   // pinned
+    uint32_t* h_fault = nullptr;   // pinned: [0..1] filled by adlhip_sync, [4] by the last adlhip_fault_check snapshot
+    hipEvent_t fault_snap = nullptr;   // recorded behind the last snapshot copy; null = none pending
 };
 
 namespace {
@@ -547,7 +550,7 @@ int onesweep_sort(adlhip_device* d, Buf data, Buf tmp, void* work, size_t n, con
         return launch(d, sizeof(key_t) == 4 ? "os_hist_u32" : "os_hist_e64", [&] {
             hipLaunchKernelGGL(kern, dim3(wgs), dim3(adlhip::kHistNT), hist_lds, d->stream, hist_src, part, (uint32_t)n, per_wg,
                                slice0, desc, total_bins, reinterpret_cast<adlhip::u32x4*>(ctrl),
-                               reinterpret_cast<adlhip::u32x4*>(status), status_vecs);
+                               reinterpret_cast<adlhip::u32x4*>(status), status_vecs, d->d_fault);
         });
     };
     switch (P) {   // pass count is a template parameter of the histogram kernel (descriptors stay in SGPRs)
@@ -628,7 +631,7 @@ int small_sort(adlhip_device* d, E* data, size_t n, const std::vector<PassPlan>&
     return d->rank_mode ? launch_small<E, 1024, 16, 1>(d, data, n, sp) : launch_small<E, 1024, 16, 0>(d, data, n, sp);
 }
 
-size_t sort_work_bytes(const adlhip_device* d, int elem_kind, size_t n)
+size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)
 {
     const size_t a = work_bytes_three_kernel(d, n);
     size_t b;
@@ -636,6 +639,19 @@ size_t sort_work_bytes(const adlhip_device* d, int elem_kind, size_t n)
     else if (elem_kind == ADLHIP_ELEM_SOA32) b = onesweep_layout(d, n, max_passes_for(d, 64), buf_tile<SoaBuf>(d, n)).total;
     else b = onesweep_layout(d, n, max_passes_for(d, 64), buf_tile<AosBuf<uint64_t>>(d, n)).total;   // as onesweep_sort<Buf>()
     return std::max(a, b);
+}
+
+// Work bytes that suffice for EVERY n' <= n with the current knobs: the requirement of one n is not monotone (a smaller
+// input selects a smaller tile, which needs more status rows), so a caller that sizes its scratch once for its largest
+// batch must get the maximum over the sizes at which the automatic tile choice changes (effective_variant: 8 and 24 MiB
+// of data).  Changing "sort.tile", "sort.digit_bits" or "sort.algo" afterwards can raise the requirement.
+size_t sort_work_bytes(const adlhip_device* d, int elem_kind, size_t n)
+{
+    const size_t esz = (elem_kind == ADLHIP_ELEM_U32) ? 4 : 8;
+    size_t need = sort_work_bytes_at(d, elem_kind, n);
+    for (size_t edge : {(size_t(8) << 20) / esz, (size_t(24) << 20) / esz - 1})
+        if (edge < n) need = std::max(need, sort_work_bytes_at(d, elem_kind, edge));
+    return need;
 }
 
 // choose the path (shared by the AoS and SoA entry points)
@@ -681,8 +697,67 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
     return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, n, plan);
 }
 
+// ---- segments finished in LDS (pass C of the hybrid sort; also a primitive of its own) ----------------------
+template <typename E, int NT, int K, int LBITS>
+int launch_segment_sort(adlhip_device* d, E* data, const uint32_t* seg_start, size_t num_segments, int low_bits,
+                        const uint32_t* gate, uint32_t gate_value)
+{
+    auto kern = adlhip::segment_sort_kernel<E, NT, K, LBITS>;
+    const size_t lds = sizeof(E) * NT * K + (size_t)(NT / 64) * (1u << LBITS) * 4 + 128;
+    if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
+    // persistent workgroups: as many as are resident at once (LDS- or wave-limited), each loops over segments
+    size_t per_cu = std::min<size_t>((size_t)160 * 1024 / lds, (size_t)32 / (NT / 64));
+    if (const char* o = getenv("ADLHIP_SEGSORT_WGS_PER_CU")) per_cu = std::max(1, atoi(o));
+    const uint32_t grid = (uint32_t)std::min<size_t>(num_segments, per_cu * (size_t)d->prop.multiProcessorCount);
+    return launch(d, sizeof(E) == 4 ? "segment_sort_u32" : "segment_sort_e64", [&] {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, d->stream, data, seg_start, (uint32_t)num_segments, (uint32_t)low_bits,
+                           gate, gate_value, d->d_fault);
+    });
+}
+
+// largest segment the finishing kernel takes for this element size and number of low bits (0: none)
+size_t segment_capacity(size_t elem_bytes, int low_bits)
+{
+    if (elem_bytes == 4) return low_bits <= 24 ? 16384 : 8192;
+    return low_bits <= 24 ? 8192 : 4096;
+}
+
+template <typename E>
+int segment_sort(adlhip_device* d, E* data, const uint32_t* seg_start, size_t num_segments, size_t max_segment, int low_bits,
+                 const uint32_t* gate, uint32_t gate_value)
+{
+    // tile by the caller's bound on the segment size; the digit width of the local passes by what fits beside the tile
+    if (sizeof(E) == 4) {
+        if (max_segment <= 4096) return launch_segment_sort<E, 256, 16, 9>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
+        if (max_segment <= 8192) return launch_segment_sort<E, 512, 16, 9>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
+        if (max_segment <= 16384 && low_bits <= 24) return launch_segment_sort<E, 512, 32, 8>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
+    } else {
+        if (max_segment <= 4096) return launch_segment_sort<E, 256, 16, 9>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
+        if (max_segment <= 8192 && low_bits <= 24) return launch_segment_sort<E, 512, 16, 8>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
+    }
+    return fail("segment sort: segments of up to %zu elements with %d key bits exceed the LDS tile (%zu)", max_segment, low_bits,
+                segment_capacity(sizeof(E), low_bits));
+}
+
 // ---- MSB partition (multi-GPU send side) -----------------------------------------------------------
 // E = uint32_t (keys) or uint64_t ({key, value} pairs: the key is the low dword, so its top byte is bits 24..31)
+
+// One three-kernel pass on the top byte: out = in, stably ordered by bits 24..31; *totals_at (device pointer into the
+// work buffer) = the 256 digit totals.
+template <typename E>
+int partition_top_byte(adlhip_device* d, const E* in, E* out, void* work, size_t work_bytes, size_t n, uint32_t** totals_at)
+{
+    if (n > kMaxElems) return fail("n too large");
+    if (!in || !out) return fail("null buffer");
+    const size_t need = work_bytes_three_kernel(d, n);
+    if (work_bytes < need || !work) return fail("work buffer too small: %zu < %zu", work_bytes, need);
+    if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) return fail("buffers must be 16-byte aligned");
+    int rc = three_kernel_pass<AosBuf<E>, 8>(d, AosBuf<E>{const_cast<E*>(in)}, AosBuf<E>{out}, work, n, 24, /*need_totals=*/true);
+    if (rc) return rc;
+    *totals_at = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + table_bytes(d, n, kMinTile));
+    return ADLHIP_SUCCESS;
+}
+
 template <typename E>
 int partition_msb(adlhip_device* d, const E* in, E* out, uint32_t* counts, void* work, size_t work_bytes, size_t n,
                          int num_buckets)
@@ -708,18 +783,31 @@ int partition_msb(adlhip_device* d, const E* in, E* out, uint32_t* counts, void*
         }
         return ADLHIP_SUCCESS;
     }
-    if (!in || !out) return fail("null buffer");
-    const size_t need = work_bytes_three_kernel(d, n);
-    if (work_bytes < need || !work) return fail("work buffer too small: %zu < %zu", work_bytes, need);
-    if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) return fail("buffers must be 16-byte aligned");
     // one three-kernel pass on the top byte (the top `lg` bits decide the bucket; ordering by the
     // whole top byte refines buckets without mixing them), then fold the 256 digit totals into buckets
-    int rc = three_kernel_pass<AosBuf<E>, 8>(d, AosBuf<E>{const_cast<E*>(in)}, AosBuf<E>{out}, work, n, 24, /*need_totals=*/true);
+    uint32_t* totals = nullptr;
+    int rc = partition_top_byte<E>(d, in, out, work, work_bytes, n, &totals);
     if (rc) return rc;
-    uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(work) + table_bytes(d, n, kMinTile));
     return launch(d, "fold_buckets", [&] {
         hipLaunchKernelGGL(adlhip::fold_buckets_kernel, dim3(1), dim3(256), 0, d->stream, (const uint32_t*)totals, counts, num_buckets);
     });
+}
+
+// the same pass with the 256 top-byte totals handed to the caller (who chooses balanced splitters from them)
+template <typename E>
+int partition_top_byte_entry(adlhip_device* d, const E* in, E* out, uint32_t* totals256, void* work, size_t work_bytes, size_t n)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!totals256) return fail("null totals pointer");
+    if (n == 0) {
+        HIPCHK(hipMemsetAsync(totals256, 0, 256 * 4, d->stream));
+        return ADLHIP_SUCCESS;
+    }
+    uint32_t* totals = nullptr;
+    int rc = partition_top_byte<E>(d, in, out, work, work_bytes, n, &totals);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(totals256, totals, 256 * 4, hipMemcpyDeviceToDevice, d->stream));
+    return ADLHIP_SUCCESS;
 }
 
 }  // namespace
@@ -727,14 +815,40 @@ int partition_msb(adlhip_device* d, const E* in, E* out, uint32_t* counts, void*
 // ================================================================================================
 extern "C" {
 
-const char* adlhip_version(void) { return "adlhip 0.1 (gfx950)"; }
+const char* adlhip_version(void) { return "adlhip 0.2 (gfx950)"; }
 const char* adlhip_last_error(void) { return g_err; }
+// internal (not in include/adlhip.h): lets the library's other translation unit (sharded.cpp) set the calling thread's
+// error text
+void adlhip_set_last_error(const char* text) { snprintf(g_err, sizeof(g_err), "%s", text ? text : ""); }
 
 int adlhip_device_count(void)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// 256-thread and 1024-thread workgroups; blocks the calling thread until the result is back
+static int run_lds_order_selftest(adlhip_device* d, int workgroups, uint32_t* mismatches)
+{
+    static uint32_t salt = 0;
+    uint32_t* slot = d->d_fault + 8;
+    HIPCHK(hipMemsetAsync(slot, 0, 4, d->stream));
+    hipLaunchKernelGGL(adlhip::lds_order_selftest_kernel, dim3(workgroups), dim3(256), 0, d->stream, slot, ++salt);
+    hipLaunchKernelGGL(adlhip::lds_order_selftest_kernel, dim3(workgroups), dim3(1024), 0, d->stream, slot, ++salt);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(d->h_fault + 8, slot, 4, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    *mismatches = d->h_fault[8];
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_selftest_lds_order(adlhip_device* d, int workgroups, uint32_t* mismatches)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!mismatches) return fail("null out pointer");
+    if (workgroups < 1 || workgroups > 65536) return fail("selftest: workgroups must be in [1,65536]");
+    return run_lds_order_selftest(d, workgroups, mismatches);
 }
 
 static int create_common(int device_idx, void* stream, bool own, adlhip_device** out)
@@ -769,19 +883,16 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
     }
     if (hipMalloc(&d->d_fault, 64) != hipSuccess || hipHostMalloc(&d->h_fault, 64) != hipSuccess ||
         hipMemsetAsync(d->d_fault, 0, 64, d->stream) != hipSuccess) {
+        if (d->d_fault) hipFree(d->d_fault);
+        if (d->h_fault) hipHostFree(d->h_fault);
+        if (own && d->stream) hipStreamDestroy(d->stream);
         delete d;
         return fail("cannot allocate the fault word");
     }
+    memset(d->h_fault, 0, 64);
     {   // self-test: are returning DS atomics lane-ordered on this device?  (enables "sort.rank" = 1)
         uint32_t mism = 1;
-        bool ok = hipMemsetAsync(d->d_fault + 8, 0, 4, d->stream) == hipSuccess;
-        if (ok) {
-            hipLaunchKernelGGL(adlhip::lds_order_selftest_kernel, dim3(64), dim3(256), 0, d->stream, d->d_fault + 8);
-            ok = hipGetLastError() == hipSuccess &&
-                 hipMemcpyAsync(&mism, d->d_fault + 8, 4, hipMemcpyDeviceToHost, d->stream) == hipSuccess &&
-                 hipStreamSynchronize(d->stream) == hipSuccess;
-        }
-        d->lds_ordered = (ok && mism == 0) ? 1 : 0;
+        d->lds_ordered = (run_lds_order_selftest(d, 64, &mism) == ADLHIP_SUCCESS && mism == 0) ? 1 : 0;
         d->rank_mode = d->lds_ordered;
     }
     if (const char* a = getenv("ADLHIP_SORT_ALGO")) { int v = atoi(a); if (v >= -1 && v <= 1) d->sort_algo = v; }
@@ -810,6 +921,7 @@ int adlhip_device_destroy(adlhip_device* d)
     for (auto& b : d->pinned_pool) hipHostFree(b.hptr);
     for (auto& p : d->pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
     for (auto e : d->event_pool) hipEventDestroy(e);
+    if (d->fault_snap) hipEventDestroy(d->fault_snap);
     hipFree(d->d_fault);
     hipHostFree(d->h_fault);
     if (d->own_stream) hipStreamDestroy(d->stream);
@@ -838,20 +950,50 @@ uint64_t adlhip_used_bytes(adlhip_device* d) { return d ? d->used_bytes : 0; }
 
 void* adlhip_stream(adlhip_device* d) { return d ? (void*)d->stream : nullptr; }
 
+static int report_fault(adlhip_device* d, uint32_t code)
+{
+    hipMemsetAsync(d->d_fault, 0, 8, d->stream);
+    if (code & 0x40000u)
+        return fail("device-side fault 0x%x (a segment exceeded the LDS tile of the finishing pass); results are invalid", code);
+    return fail("device-side fault 0x%x (look-back wait exceeded its bound); results are invalid", code);
+}
+
 int adlhip_sync(adlhip_device* d)
 {
     if (bind(d)) return ADLHIP_FAILURE;
-    // pick up the device-side fault word together with the drain
-    HIPCHK(hipMemcpyAsync(d->h_fault, d->d_fault, 4, hipMemcpyDeviceToHost, d->stream));
+    // pick up the device-side fault words together with the drain
+    HIPCHK(hipMemcpyAsync(d->h_fault, d->d_fault, 8, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     reap_staging(d, true);
-    if (d->h_fault[0] != 0) {
-        const uint32_t code = d->h_fault[0];
-        d->h_fault[0] = 0;
-        hipMemsetAsync(d->d_fault, 0, 4, d->stream);
-        return fail("device-side fault 0x%x (look-back wait exceeded its bound); results are invalid", code);
+    uint32_t code = d->h_fault[1];
+    if (d->fault_snap) {   // a snapshot taken before this drain has landed too
+        code |= d->h_fault[4];
+        d->h_fault[4] = 0;
+        hipEventDestroy(d->fault_snap);
+        d->fault_snap = nullptr;
+    }
+    if (code != 0) {
+        d->h_fault[0] = d->h_fault[1] = 0;
+        return report_fault(d, code);
     }
     return ADLHIP_SUCCESS;
+}
+
+int adlhip_fault_check(adlhip_device* d)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    uint32_t code = 0;
+    if (d->fault_snap) {
+        if (hipEventQuery(d->fault_snap) != hipSuccess) return ADLHIP_SUCCESS;   // the last snapshot is still in flight
+        code = d->h_fault[4];
+        d->h_fault[4] = 0;
+    } else {
+        HIPCHK(hipEventCreateWithFlags(&d->fault_snap, hipEventDisableTiming));
+    }
+    if (code != 0) report_fault(d, code);   // clears the device words BEFORE the next snapshot is taken: reported once
+    HIPCHK(hipMemcpyAsync(d->h_fault + 4, d->d_fault + 1, 4, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipEventRecord(d->fault_snap, d->stream));
+    return code != 0 ? ADLHIP_FAILURE : ADLHIP_SUCCESS;
 }
 
 int adlhip_flush(adlhip_device* d) { return bind(d); }
@@ -1061,6 +1203,21 @@ int adlhip_radix_sort_soa32(adlhip_device* d, uint32_t* keys, uint32_t* vals, ui
     return run_sort<SoaBuf>(d, SoaBuf{keys, vals}, SoaBuf{tmp_keys, tmp_vals}, work, n, plan);
 }
 
+int adlhip_segment_sort(adlhip_device* d, int elem_kind, void* data, const uint32_t* seg_start, size_t num_segments,
+                        size_t max_segment, int low_bits)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (elem_kind != ADLHIP_ELEM_U32 && elem_kind != ADLHIP_ELEM_KV32) return fail("segment sort: u32 keys or {key, value} pairs only");
+    if (low_bits < 1 || low_bits > 27) return fail("segment sort: low_bits must be in [1,27], got %d", low_bits);
+    if (num_segments == 0) return ADLHIP_SUCCESS;
+    if (!data || !seg_start) return fail("null buffer passed to segment sort");
+    if (num_segments > 0x7fffffffull) return fail("segment sort: too many segments");
+    if (!d->lds_ordered) return fail("segment sort needs lane-ordered DS atomics; the device self-test failed");
+    if (elem_kind == ADLHIP_ELEM_U32)
+        return segment_sort<uint32_t>(d, static_cast<uint32_t*>(data), seg_start, num_segments, max_segment, low_bits, nullptr, 0u);
+    return segment_sort<uint64_t>(d, static_cast<uint64_t*>(data), seg_start, num_segments, max_segment, low_bits, nullptr, 0u);
+}
+
 // ---- scan ---------------------------------------------------------------------------------------
 
 int adlhip_scan_scratch_bytes(adlhip_device* d, size_t n, size_t* work_bytes)
@@ -1126,6 +1283,19 @@ int adlhip_partition_msb_kv32(adlhip_device* d, const void* in, void* out, uint3
 {
     return partition_msb<uint64_t>(d, static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), counts, work, work_bytes, n,
                                    num_buckets);
+}
+
+int adlhip_partition_top_byte_u32(adlhip_device* d, const uint32_t* in, uint32_t* out, uint32_t* totals256, void* work,
+                                  size_t work_bytes, size_t n)
+{
+    return partition_top_byte_entry<uint32_t>(d, in, out, totals256, work, work_bytes, n);
+}
+
+int adlhip_partition_top_byte_kv32(adlhip_device* d, const void* in, void* out, uint32_t* totals256, void* work,
+                                   size_t work_bytes, size_t n)
+{
+    return partition_top_byte_entry<uint64_t>(d, static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), totals256, work,
+                                              work_bytes, n);
 }
 
 // ---- synthetic inputs ---------------------------------------------------------------------------

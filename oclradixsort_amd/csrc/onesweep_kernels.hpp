@@ -80,6 +80,15 @@ constexpr int kLookbackWindow = 4;         // predecessor status rows fetched pe
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// Device fault words: fault[0] is "live" -- waiters of the sort that is running poll it so that a broken hand-off
+// drains in one bound; the first kernel of every sort clears it, so one failure cannot poison later sorts.
+// fault[1] is sticky: it keeps every code raised since the host last looked (adlhip_sync / adlhip_fault_check).
+__device__ __forceinline__ void raise_fault(uint32_t* fault, uint32_t code)
+{
+    atomicOr(fault, code);
+    atomicOr(fault + 1, code);
+}
+
 // joint-histogram bins of a pass: (chain, digit) -> kChains << nbits
 __host__ __device__ inline uint32_t joint_bins(int nbits) { return (uint32_t)kChains << nbits; }
 
@@ -97,7 +106,8 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
                                                                 uint32_t* __restrict__ partial, uint32_t n,
                                                                 uint32_t chunk, uint32_t slice0, PassDesc desc,
                                                                 uint32_t total_bins, u32x4* __restrict__ tickets,
-                                                                u32x4* __restrict__ status, size_t status_vecs)
+                                                                u32x4* __restrict__ status, size_t status_vecs,
+                                                                uint32_t* __restrict__ fault)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
@@ -106,8 +116,10 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
     // drain under the key stream, instead of two memset launches in front of every sort.
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
-        if (blockIdx.x == 0)
+        if (blockIdx.x == 0) {
             for (int i = tid; i < kTicketVecs; i += kHistNT) tickets[i] = z;
+            if (tid == 0) fault[0] = 0u;   // the live fault word belongs to the sort that starts here
+        }
         const size_t stride = (size_t)gridDim.x * kHistNT;
         for (size_t i = (size_t)blockIdx.x * kHistNT + (size_t)tid; i < status_vecs; i += stride) status[i] = z;
     }
@@ -364,8 +376,8 @@ __device__ __forceinline__ u32x4 lookback_exclusive4(__amdgpu_buffer_rsrc_t rsrc
                 // hand-off drains in one bound, not one bound per tile)
                 if (spins > kSpinBound ||
                     ((spins & 1023u) == 0u && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                    atomicOr(fault, 0x20000u | (uint32_t)start_bit);
-                    return excl;   // results are invalid; the host is told at adlhip_sync()
+                    raise_fault(fault, 0x20000u | (uint32_t)start_bit);
+                    return excl;   // results are invalid; the host is told at adlhip_sync() / adlhip_fault_check()
                 }
                 __builtin_amdgcn_s_sleep(1);
                 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((uint32_t)ti * (uint32_t)BINS + 4u * (uint32_t)lane) * 4u,

@@ -931,31 +931,48 @@ __global__ __launch_bounds__(256) void fill_pattern16_kernel(uint4* __restrict__
     if (tail8 && blockIdx.x == 0 && threadIdx.x == 0) *tail8 = tail_pattern;
 }
 
-// Device self-test for the RANK == 1 path: do returning DS atomics of one wave-instruction resolve
-// colliding lanes in ascending lane order, and do successive instructions of a wave apply in order?
-// Compares ds_add_rtn ranks with ballot/mbcnt ranks over pseudo-random digits for 1, 2, 16 and 256
-// bins; *mismatches stays 0 iff they agree everywhere.
-__global__ __launch_bounds__(256) void lds_order_selftest_kernel(uint32_t* __restrict__ mismatches)
+// Device self-test for the RANK == 1 path: do returning DS atomics of one wave-instruction resolve colliding
+// lanes in ascending lane order, and do successive instructions of a wave apply in order?  Compares ds_add_rtn
+// ranks with ballot/mbcnt ranks over pseudo-random digits for 1, 2, 16 and 256 bins; *mismatches stays 0 iff they
+// agree everywhere.  Shaped like the kernels that rely on it: up to 1024-thread workgroups (every wave hammering
+// its own counters, so the LDS unit is contended the way it is in a pass), sixteen atomics back to back per lane,
+// and rounds with a pseudo-random subset of the lanes switched off (partial waves: tail tiles, segment ends).
+// It also runs on its own stream beside real sorts (adlhip_selftest_lds_order; tests/test_gpu_parity.py).
+__global__ __launch_bounds__(1024) void lds_order_selftest_kernel(uint32_t* __restrict__ mismatches, uint32_t salt)
 {
-    __shared__ uint32_t c_atomic[4][256];
-    __shared__ uint32_t c_ballot[4][256];
+    __shared__ uint32_t c_atomic[16][256];
+    __shared__ uint32_t c_ballot[16][256];
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
     uint32_t bad = 0u;
     for (int lg = 0; lg <= 8; lg += (lg < 1 ? 1 : (lg < 4 ? 3 : 4))) {   // bins = 1, 2, 16, 256
         const uint32_t bins = 1u << lg;
-        for (int b = lane; b < 256; b += 64) { c_atomic[w][b] = 0u; c_ballot[w][b] = 0u; }
-        for (int j = 0; j < 16; ++j) {
-            uint32_t h = (blockIdx.x * 256u + threadIdx.x) * 16u + (uint32_t)j + bins * 0x9E3779B9u;
-            h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
-            const uint32_t d = h & (bins - 1u);
-            const uint32_t got = __hip_atomic_fetch_add(&c_atomic[w][d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint64_t m = match_digit<8>(d);
-            const uint32_t below = mbcnt64(m);
-            const uint32_t old = __hip_atomic_load(&c_ballot[w][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (below == 0u)
-                __hip_atomic_fetch_add(&c_ballot[w][d], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            bad += (got != old + below) ? 1u : 0u;
+        for (int part = 0; part < 2; ++part) {   // all lanes on / a pseudo-random subset on
+            for (int b = lane; b < 256; b += 64) { c_atomic[w][b] = 0u; c_ballot[w][b] = 0u; }
+            uint32_t d[16], got[16];
+            bool on[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) * 16u + (uint32_t)j + bins * 0x9E3779B9u + salt * 0x85EBCA6Bu;
+                h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+                d[j] = h & (bins - 1u);
+                on[j] = part == 0 || ((h >> 20) & 3u) != 0u;
+            }
+            // the atomics back to back, as the ranking loops issue them
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (on[j]) got[j] = __hip_atomic_fetch_add(&c_atomic[w][d[j]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (on[j]) {   // ballots inside the branch see the active lanes only (~ballot would count the others: mask them)
+                    const uint64_t m = match_digit<8>(d[j]) & __ballot(true);
+                    const uint32_t below = mbcnt64(m);
+                    const uint32_t old = __hip_atomic_load(&c_ballot[w][d[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    if (below == 0u)
+                        __hip_atomic_fetch_add(&c_ballot[w][d[j]], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    bad += (got[j] != old + below) ? 1u : 0u;
+                }
+            }
         }
     }
     if (bad) atomicAdd(mismatches, bad);

@@ -2,10 +2,14 @@
 (backend "nccl" = RCCL over xGMI on ROCm).  No reference counterpart -- the reference drives exactly
 one device (Adl/Adl.h:90-94); SURVEY.md section 8e describes this step.
 
-Radix order is decided first by the most significant bits, so rank g of G owns the keys whose top
-log2(G) bits equal g.  Per sort:
-  1. local stable partition of the rank's keys into G contiguous segments by their top bits
-     (adlhip_partition_msb_u32: one count -> scan -> scatter pass on the top byte);
+Radix order is decided first by the most significant bits, so rank g of G owns a contiguous range of top-byte
+values: with balance=False the keys whose top log2(G) bits equal g; with balance=True (default) a range chosen
+from the GLOBAL top-byte histogram so that every rank receives about the same number of keys whatever the key
+distribution (balanced splitters; rank order stays key order).  Per sort:
+  1. local stable partition of the rank's keys by their top byte (adlhip_partition_top_byte_u32: one count ->
+     scan -> scatter pass), which also yields the 256 top-byte totals; balance=True: ONE 2-KiB all-reduce of the
+     totals, then every rank cuts the byte range at the same G-1 places (choose_splitters, device-side torch
+     ops, no host sync) and folds its own totals into G segment sizes;
   2. ONE small all-gather of the G segment sizes (G x G matrix) -- the only host sync;
   3. ONE all_to_all_single of the segments with those split sizes.  On a fully connected xGMI node
      every pair of GPUs has its own link, so all G-1 links of a GPU carry traffic at once;
@@ -35,6 +39,29 @@ from . import _lib
 from ._lib import check
 from .adl import Buffer, Config, DeviceUtils
 from .pprims import ELEM_KV32, ELEM_U32, Pprims
+
+
+def choose_splitters(global_totals, num_ranks):
+    """Cut the 256 top-byte values into `num_ranks` contiguous ranges of near-equal population.
+    global_totals: int64 tensor [256] (the all-reduced top-byte histogram, on any device).  Returns an int64 tensor
+    bounds[num_ranks + 1] on the same device, bounds[0] = 0, bounds[-1] = 256, non-decreasing: rank g owns the top
+    bytes [bounds[g], bounds[g+1]).  Every cut is the byte boundary whose cumulative count is nearest to
+    g * total / num_ranks, so a rank's share differs from the mean by at most the population of one byte value
+    (uniform keys: exactly the fixed top-bits ownership).  Pure tensor ops: deterministic, identical on every
+    rank, no host synchronisation."""
+    G = int(num_ranks)
+    t = global_totals.to(torch.int64)
+    cum = torch.cumsum(t, 0)                                     # cum[b] = keys with top byte <= b
+    total = cum[-1]
+    g = torch.arange(1, G, dtype=torch.int64, device=t.device)
+    target = (total * g) // G
+    idx = torch.searchsorted(cum, target).clamp(max=255)         # first byte b with cum[b] >= target
+    hi = cum[idx]
+    lo = torch.where(idx > 0, cum[(idx - 1).clamp(min=0)], torch.zeros_like(hi))
+    cut = torch.where((hi - target) <= (target - lo), idx + 1, idx)     # boundary after byte idx, or before it
+    cut = torch.cummax(cut, 0).values if G > 1 else cut
+    zero = torch.zeros(1, dtype=torch.int64, device=t.device)
+    return torch.cat([zero, cut, zero + 256])
 
 
 class _Stage:
@@ -165,7 +192,9 @@ class HipBackend:
                 for st in (self._exchange, self._sorting):
                     if st is not None:
                         t.record_stream(st.stream)
-            cap = int(n) + int(n) // 16 + 1024
+            # receive slots: balanced splitters keep a rank's share within ~1.25x of the mean, so a quarter of headroom
+            # means later batches of the same size never reallocate; partition slots hold exactly the batch
+            cap = int(n) + int(n) // (4 if pool is self._recv else 16) + 1024
             t = torch.empty(cap, dtype=dtype, device=self.torch_device)
             pool[slot] = t
         return t[:n]
@@ -174,7 +203,7 @@ class HipBackend:
         """Allocate everything a sort_stream over batches of about n elements per rank needs -- the receive and partition
         slots, both stages' scratch -- now, so that the first batches do not pay for it (allocations sync the device)."""
         n = int(n)
-        cap = n + n // 16 + 1024
+        cap = n + n // 4 + 1024
         for slot in range(self.pipeline_depth):
             self.recv_buffer(slot, cap, dtype)
             self.part_buffer(slot, n, dtype)
@@ -237,6 +266,32 @@ class HipBackend:
         return out, counts
 
 
+    def partition_top_byte(self, keys, out=None):
+        """As partition_msb, but ordered by the whole top byte and with the 256 top-byte totals (int32 CUDA tensor)
+        instead of per-bucket counts: the caller cuts the byte range wherever the global histogram says."""
+        ct = self._ct
+        st = self._cur
+        n = keys.numel()
+        if keys.dtype not in (torch.int32, torch.int64):
+            raise TypeError("sharded sort takes int32 (u32 keys) or int64 ({key, value} pairs) tensors, got %s" % keys.dtype)
+        pairs = keys.dtype == torch.int64
+        if out is None:
+            out = self.empty(n, keys.dtype)
+        totals = torch.empty(256, dtype=torch.int32, device=self.torch_device)
+        lib = _lib.load()
+        tb = ct.c_size_t()
+        wb = ct.c_size_t()
+        check(lib.adlhip_radix_sort_scratch_bytes(st.device._h, 1 if pairs else 0, n, ct.byref(tb), ct.byref(wb)), "scratch_bytes")
+        if st.work is None or st.work.getSize() < wb.value:
+            if st.work is not None:
+                DeviceUtils.waitForCompletion(st.device)
+                st.work.release()
+            st.work = Buffer(st.device, wb.value + wb.value // 8, np.uint8)
+        fn = lib.adlhip_partition_top_byte_kv32 if pairs else lib.adlhip_partition_top_byte_u32
+        check(fn(st.device._h, ct.c_void_p(keys.data_ptr()), ct.c_void_p(out.data_ptr()), ct.c_void_p(totals.data_ptr()),
+                 st.work.ptr(), st.work.getSize(), n), "adlhip_partition_top_byte")
+        return out, totals
+
     def local_sort(self, keys):
         """In-place ascending sort (by key, stable) of an int32 CUDA tensor holding u32 bit patterns or an int64
         CUDA tensor holding {key, value} pairs, on the stage of the scope we are in."""
@@ -251,6 +306,9 @@ class HipBackend:
                 st.reserved = cap * keys.element_size()
                 st.pprims.reserve(st.device, ELEM_U32 if keys.dtype == torch.int32 else ELEM_KV32, cap)
             st.pprims.radixSort(st.device, self._wrap(st.device, keys), n)
+            # the stage's stream is synchronised by torch, never by adlhip_sync: pick up device-side faults (look-back
+            # time-out) of earlier, completed batches here -- stream-ordered, non-blocking
+            st.device.checkFault()
         return keys
 
 
@@ -261,9 +319,12 @@ class ShardedRadixSort:
     (and, for sort_stream, the pipeline plumbing: exchange_scope / sort_scope / event / wait /
     recv_buffer / part_buffer / pipeline_depth)."""
 
-    def __init__(self, backend, group=None, rehearse_buckets=0):
+    def __init__(self, backend, group=None, rehearse_buckets=0, balance=True):
         self.backend = backend
         self.group = group
+        # balanced splitters (SURVEY section 8e step 1): ownership follows the global top-byte histogram
+        self.balance = bool(balance) and hasattr(backend, "partition_top_byte")
+        self.last_bounds = None     # int64 tensor [G+1] of the last balanced sort: rank g owns top bytes [b[g], b[g+1])
         # development aid: partition into this many buckets even if the world is smaller (the counts are folded back
         # to one per rank), so that a 1-GPU box pays the partition pass an 8-GPU rank would pay
         self.rehearse_buckets = int(rehearse_buckets)
@@ -278,6 +339,16 @@ class ShardedRadixSort:
     def _partition(self, keys, out=None):
         """Partition by the top bits into one contiguous segment per rank; returns (partitioned, counts[G])."""
         G = self.world
+        if self.balance and not self.rehearse_buckets:
+            part, totals = self.backend.partition_top_byte(keys, out=out)
+            glob = totals.to(torch.int64)
+            if dist.is_initialized() and G > 1:
+                dist.all_reduce(glob, group=self.group)          # 2 KiB: the global top-byte histogram
+            bounds = choose_splitters(glob, G)
+            lc = torch.cat([torch.zeros(1, dtype=torch.int64, device=totals.device), torch.cumsum(totals.to(torch.int64), 0)])
+            counts = (lc[bounds[1:]] - lc[bounds[:-1]]).to(totals.dtype)
+            self.last_bounds = bounds
+            return part, counts
         B = max(G, self.rehearse_buckets)
         part, counts = self.backend.partition_msb(keys, B, out=out)
         if B != G:

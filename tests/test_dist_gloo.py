@@ -82,6 +82,20 @@ class NumpyBackend:
             res = out
         return res, torch.from_numpy(counts)
 
+    def partition_top_byte(self, keys, out=None):
+        self.log.append(("partition", self._scope))
+        pairs = keys.dtype == torch.int64
+        k = keys.numpy().view(np.uint64 if pairs else np.uint32)
+        key32 = (k & np.uint64(0xffffffff)).astype(np.uint32) if pairs else k
+        top = (key32 >> np.uint32(24)).astype(np.int64)
+        order = np.argsort(top, kind="stable")
+        totals = np.bincount(top, minlength=256).astype(np.int32)
+        res = torch.from_numpy(k[order].view(np.int64 if pairs else np.int32).copy())
+        if out is not None:
+            out.copy_(res)
+            res = out
+        return res, torch.from_numpy(totals)
+
     def local_sort(self, keys):
         import oracle
         self.log.append(("sort", self._scope))
@@ -94,7 +108,7 @@ class NumpyBackend:
         return keys
 
 
-def _worker(rank, world, port, n_per_rank, skew, out_dir):
+def _worker(rank, world, port, n_per_rank, skew, out_dir, balance=True):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -105,10 +119,12 @@ def _worker(rank, world, port, n_per_rank, skew, out_dir):
         keys = oracle.keys_u32(n_per_rank, seed=77, first_index=rank * n_per_rank)
         if skew:   # most keys in the low bucket: ragged exchange, one rank receives almost everything
             keys = np.where(np.arange(n_per_rank) % 10 != 0, keys >> np.uint32(3), keys).astype(np.uint32)
-        sorter = ShardedRadixSort(NumpyBackend())
+        sorter = ShardedRadixSort(NumpyBackend(), balance=balance)
         got = sorter.sort(torch.from_numpy(keys.view(np.int32).copy()))
         np.save(os.path.join(out_dir, "out_%d.npy" % rank), got.numpy().view(np.uint32))
         np.save(os.path.join(out_dir, "in_%d.npy" % rank), keys)
+        if balance:
+            np.save(os.path.join(out_dir, "bounds_%d.npy" % rank), sorter.last_bounds.numpy())
         send, recv = sorter.last_splits
         assert sum(send) == n_per_rank and sum(recv) == got.numel()
     finally:
@@ -160,10 +176,10 @@ def _free_port():
 
 
 @pytest.mark.parametrize("skew", [False, True], ids=["uniform", "skewed"])
-def test_sharded_sort_world2_gloo(tmp_path, skew):
+def test_sharded_sort_world2_gloo_fixed_ownership(tmp_path, skew):
     import oracle
     world, n = 2, 50021
-    mp.spawn(_worker, args=(world, _free_port(), n, skew, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, skew, str(tmp_path), False), nprocs=world, join=True)
     ins = [np.load(tmp_path / ("in_%d.npy" % r)) for r in range(world)]
     outs = [np.load(tmp_path / ("out_%d.npy" % r)) for r in range(world)]
     want = oracle.sort_u32(np.concatenate(ins))
@@ -171,6 +187,57 @@ def test_sharded_sort_world2_gloo(tmp_path, skew):
     assert np.array_equal(got, want)
     for r, o in enumerate(outs):                     # bucket ownership: top bit == rank
         assert o.size == 0 or ((o >> np.uint32(31)) == r).all()
+    if skew:                                         # what balanced splitters are for: one rank gets nearly everything
+        assert outs[0].size > 0.9 * sum(o.size for o in outs)
+
+
+@pytest.mark.parametrize("skew", [False, True], ids=["uniform", "skewed"])
+def test_sharded_sort_world2_gloo_balanced_splitters(tmp_path, skew):
+    """Balanced splitters: ownership follows the all-reduced top-byte histogram.  On the skewed
+    input fixed top-bit ownership sends > 90 % of the keys to rank 0 (previous test); here no rank may receive more
+    than 1.25x the mean, rank order must still be key order, and the result must be bit-exact."""
+    import oracle
+    world, n = 2, 50021
+    mp.spawn(_worker, args=(world, _free_port(), n, skew, str(tmp_path), True), nprocs=world, join=True)
+    ins = [np.load(tmp_path / ("in_%d.npy" % r)) for r in range(world)]
+    outs = [np.load(tmp_path / ("out_%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(np.concatenate(outs), oracle.sort_u32(np.concatenate(ins)))
+    b0, b1 = (np.load(tmp_path / ("bounds_%d.npy" % r)) for r in range(world))
+    assert np.array_equal(b0, b1) and b0[0] == 0 and b0[-1] == 256 and np.all(np.diff(b0) >= 0)
+    for r, o in enumerate(outs):                     # ownership: top byte inside the rank's range
+        assert o.size == 0 or (((o >> np.uint32(24)) >= b0[r]) & ((o >> np.uint32(24)) < b0[r + 1])).all()
+    mean = sum(o.size for o in outs) / world
+    assert max(o.size for o in outs) <= 1.25 * mean, [o.size for o in outs]
+    if not skew:
+        assert abs(int(b0[1]) - 128) <= 2             # uniform keys: (nearly) the fixed top-bit ownership
+
+
+def test_choose_splitters_properties():
+    from oclradixsort_amd.dist import choose_splitters
+    rng = np.random.RandomState(5)
+    for G in (1, 2, 4, 8, 16):
+        for trial in range(20):
+            kind = trial % 5
+            if kind == 0:
+                h = np.full(256, 1000, dtype=np.int64)
+            elif kind == 1:
+                h = rng.randint(0, 5000, 256).astype(np.int64)
+            elif kind == 2:
+                h = (rng.zipf(1.3, 256) * 10).astype(np.int64)[rng.permutation(256)]
+            elif kind == 3:
+                h = np.zeros(256, dtype=np.int64); h[rng.randint(0, 256, 5)] = rng.randint(1, 10**6, 5)
+            else:
+                h = np.zeros(256, dtype=np.int64)       # empty input
+            b = choose_splitters(torch.from_numpy(h), G).numpy()
+            assert b.shape == (G + 1,) and b[0] == 0 and b[-1] == 256 and np.all(np.diff(b) >= 0)
+            share = np.add.reduceat(np.concatenate([h, [0]]), b[:-1].clip(max=256))[:G] if h.sum() else np.zeros(G)
+            share = np.array([h[b[g]:b[g + 1]].sum() for g in range(G)])
+            assert share.sum() == h.sum()
+            if h.sum():
+                # a rank's share differs from the mean by at most one byte value's population on either side
+                assert share.max() <= h.sum() / G + 2 * h.max() + 1
+            if kind == 0 and 256 % G == 0:
+                assert list(b) == [g * (256 // G) for g in range(G + 1)]
 
 
 def test_pipelined_sort_stream_world2_gloo(tmp_path):
@@ -185,8 +252,6 @@ def test_pipelined_sort_stream_world2_gloo(tmp_path):
         ins = [np.load(tmp_path / ("in_%d_%d.npy" % (b, r))) for r in range(world)]
         outs = [np.load(tmp_path / ("out_%d_%d.npy" % (b, r))) for r in range(world)]
         assert np.array_equal(np.concatenate(outs), oracle.sort_u32(np.concatenate(ins))), "batch %d" % b
-        for r, o in enumerate(outs):
-            assert o.size == 0 or ((o >> np.uint32(31)) == r).all()
 
 
 def test_pipelined_key_value_sort_stream_world2_gloo(tmp_path):
