@@ -136,7 +136,14 @@ struct Device {
 
 // TYPE_CL: the HIP back-end through the C ABI (replaces DeviceCL, Adl/CL/AdlCL.inl:23-143)
 struct DeviceHip : public Device {
-    DeviceHip() : Device(TYPE_CL), m_hip(0) {}
+    DeviceHip() : Device(TYPE_CL), m_hip(0), m_ownsHip(true) {}
+    // wrap a handle that someone else owns (a rank of an adlhip_group, Tahoe::ShardedSort): release() leaves it alone
+    void attach(adlhip_device* hip)
+    {
+        m_procType = Config::DEVICE_GPU;
+        m_hip = hip;
+        m_ownsHip = false;
+    }
     void initialize(const Config& cfg)
     {
         m_procType = cfg.m_type;
@@ -146,10 +153,8 @@ struct DeviceHip : public Device {
     }
     void release()
     {
-        if (m_hip) {
-            ADLHIP_CALL(adlhip_device_destroy(m_hip));
-            m_hip = 0;
-        }
+        if (m_hip && m_ownsHip) ADLHIP_CALL(adlhip_device_destroy(m_hip));
+        m_hip = 0;
     }
     void waitForCompletion() const
     {
@@ -210,6 +215,7 @@ struct DeviceHip : public Device {
     adlhip_device* hip() const { return m_hip; }
 
     adlhip_device* m_hip;
+    bool m_ownsHip;
 };
 
 // TYPE_HOST: the CPU "device" (Adl/Host/AdlHost.inl:8-72): plain memory, synchronous copies, identity map

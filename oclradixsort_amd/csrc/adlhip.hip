@@ -715,6 +715,21 @@ int launch_segment_sort(adlhip_device* d, E* data, const uint32_t* seg_start, si
     });
 }
 
+template <typename E, int K, int LBITS>
+int launch_segment_sort_wave(adlhip_device* d, E* data, const uint32_t* seg_start, size_t num_segments, int low_bits,
+                             const uint32_t* gate, uint32_t gate_value)
+{
+    constexpr int WAVES = 4;
+    auto kern = adlhip::segment_sort_wave_kernel<E, K, LBITS, WAVES>;
+    const size_t lds = (size_t)WAVES * (sizeof(E) * 64 * K + (size_t)(1u << LBITS) * 4);
+    if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
+    const uint32_t grid = (uint32_t)((num_segments + WAVES - 1) / WAVES);
+    return launch(d, sizeof(E) == 4 ? "segment_sort_wave_u32" : "segment_sort_wave_e64", [&] {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, d->stream, data, seg_start, (uint32_t)num_segments,
+                           (uint32_t)low_bits, gate, gate_value, d->d_fault);
+    });
+}
+
 // largest segment the finishing kernel takes for this element size and number of low bits (0: none)
 size_t segment_capacity(size_t elem_bytes, int low_bits)
 {
@@ -726,6 +741,16 @@ template <typename E>
 int segment_sort(adlhip_device* d, E* data, const uint32_t* seg_start, size_t num_segments, size_t max_segment, int low_bits,
                  const uint32_t* gate, uint32_t gate_value)
 {
+    // segments that fit one wave's registers: a wave per segment, no workgroup barriers (low_bits <= 18: two passes)
+    static const bool no_wave = getenv("ADLHIP_SEGSORT_NO_WAVE") != nullptr;
+    if (!no_wave && low_bits <= 18) {
+        if (sizeof(E) == 4) {
+            if (max_segment <= 1536) return launch_segment_sort_wave<E, 24, 9>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
+            if (max_segment <= 2560) return launch_segment_sort_wave<E, 40, 9>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
+        } else {
+            if (max_segment <= 1280) return launch_segment_sort_wave<E, 20, 9>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
+        }
+    }
     // tile by the caller's bound on the segment size; the digit width of the local passes by what fits beside the tile
     if (sizeof(E) == 4) {
         if (max_segment <= 4096) return launch_segment_sort<E, 256, 16, 9>(d, data, seg_start, num_segments, low_bits, gate, gate_value);

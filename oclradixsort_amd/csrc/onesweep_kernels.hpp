@@ -397,9 +397,9 @@ __device__ __forceinline__ u32x4 lookback_exclusive4(__amdgpu_buffer_rsrc_t rsrc
 // The pass kernel: one tile per workgroup.
 //   ticket (chain chosen by blockIdx % 16, next chains probed when one is exhausted)
 //   load (wave-striped) -> rank (one returning DS atomic per element)                 | barrier A
-//   wave 0 ("bookkeeping wave", 4 digits per lane): fold the per-wave counts, PUBLISH the tile's
-//     digit counts at once, DPP-scan them into tile offsets, write (wave, digit) tile positions | barrier B
-//   all waves: scatter elements to their tile-sorted LDS slot;
+//   every wave: fold the per-wave counts of all waves (4 digits per lane), DPP-scan the digit totals into tile offsets and
+//     write the 16-bit tile positions of its own (wave, digit) runs; wave 0 also PUBLISHES the tile's digit counts at once
+//   all waves: scatter elements to their tile-sorted LDS slot (no barrier in between: a wave reads only its own positions);
 //   wave 0 then: look-back over its chain, publish inclusive prefix, global offsets    | barrier C
 //   write-out: consecutive lanes store consecutive elements of a digit's run.
 // ------------------------------------------------------------------------------------------
@@ -533,37 +533,43 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTab
     __syncthreads();   // A
     ADLHIP_STAMP(tile, 3);
 
-    // ---- bookkeeping wave ---------------------------------------------------------------------------
+    // ---- every wave: fold the per-wave counts, scan the digit totals, write the tile positions of ITS OWN (wave, digit)
+    // runs.  (One bookkeeping wave used to do this for all eight while seven waited: 2.2K cycles + a barrier of a 28K-cycle
+    // tile.  Each wave now reads the NW count rows itself -- 8 x 16 bytes per lane -- and writes one row of 16-bit
+    // positions that only it will read, so no barrier separates this from the LDS scatter.)
     u32x4 cnt4 = {0u, 0u, 0u, 0u};
     u32x4 toff4 = {0u, 0u, 0u, 0u};
-    if (w == 0) {   // whole wave: the DPP scan needs all 64 lanes active
+    uint16_t* __restrict__ my_wpos = reinterpret_cast<uint16_t*>(smem + C::OFF_WPOS) + w * BINS;
+    {
+        u32x4 pre4 = {0u, 0u, 0u, 0u};   // elements of my digits in the waves before mine
         if (lane < BK_LANES) {
 #pragma unroll
-            for (int i = 0; i < NW; ++i) cnt4 += *reinterpret_cast<const u32x4*>(s_wcnt + i * BINS + 4 * lane);
-            // publish this tile's digit counts right away (the chain's first tile: they ARE its prefix)
-            const uint32_t flag = index == 0u ? kFlagPfx : kFlagAgg;
-            __builtin_amdgcn_raw_buffer_store_b128(cnt4 | flag, rsrc, (tile * (uint32_t)BINS + 4u * (uint32_t)lane) * 4u, 0,
-                                                   16 /* sc1 */);
+            for (int i = 0; i < NW; ++i) {
+                const u32x4 r = *reinterpret_cast<const u32x4*>(s_wcnt + i * BINS + 4 * lane);
+                cnt4 += r;
+                if (i < w) pre4 += r;
+            }
+            if (w == 0) {
+                // publish this tile's digit counts right away (the chain's first tile: they ARE its prefix)
+                const uint32_t flag = index == 0u ? kFlagPfx : kFlagAgg;
+                __builtin_amdgcn_raw_buffer_store_b128(cnt4 | flag, rsrc, (tile * (uint32_t)BINS + 4u * (uint32_t)lane) * 4u, 0,
+                                                       16 /* sc1 */);
+            }
         }
         const uint32_t s4 = cnt4.x + cnt4.y + cnt4.z + cnt4.w;
-        const uint32_t ex = wave_incl_scan_u32(s4) - s4;
+        const uint32_t ex = wave_incl_scan_u32(s4) - s4;   // whole wave: the DPP scan needs all 64 lanes active
         toff4.x = ex;
         toff4.y = ex + cnt4.x;
         toff4.z = toff4.y + cnt4.y;
         toff4.w = toff4.z + cnt4.z;
         if (lane < BK_LANES) {
-            u32x4 run = toff4;
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {   // second sweep over the rows keeps one row live, not NW
-                u32x4* row = reinterpret_cast<u32x4*>(s_wcnt + i * BINS + 4 * lane);
-                const u32x4 ci = *row;
-                *row = run;   // tile position of (wave i, digit)'s first element
-                run += ci;
-            }
+            const u32x4 p4 = toff4 + pre4;   // < TILE <= 65536
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 packed = {p4.x | (p4.y << 16), p4.z | (p4.w << 16)};
+            *reinterpret_cast<u32x2*>(my_wpos + 4 * lane) = packed;
         }
     }
     ADLHIP_STAMP(tile, 4);
-    __syncthreads();   // B
     ADLHIP_STAMP(tile, 5);
 
     // ---- scatter into tile-sorted order -----------------------------------------------------------
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTab
         for (int j0 = 0; j0 < K; j0 += CH) {
             uint32_t pos[CH];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) pos[j] = my_wcnt[digit_of<NBITS>(e[(j0 + j < K) ? j0 + j : K - 1], start_bit)];
+            for (int j = 0; j < CH; ++j) pos[j] = my_wpos[digit_of<NBITS>(e[(j0 + j < K) ? j0 + j : K - 1], start_bit)];
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 if (j0 + j < K) {   // K need not be a multiple of CH

@@ -141,7 +141,10 @@ struct TileCfg {
     static constexpr size_t OFF_GOFF = OFF_WCNT + sizeof(uint32_t) * NW * BINS;
     static constexpr size_t OFF_WSUM = OFF_GOFF + sizeof(uint32_t) * BINS;
     static constexpr size_t OFF_MISC = OFF_WSUM + 16 * ((NW + 1 + 3) / 4) * 4;
-    static constexpr size_t LDS_BYTES = OFF_MISC + 64;
+    // one-sweep pass: tile positions of the (wave, digit) runs as 16-bit values (a tile has fewer than 65536 elements)
+    static_assert(TILE <= 65536, "16-bit tile positions");
+    static constexpr size_t OFF_WPOS = OFF_MISC + 64;
+    static constexpr size_t LDS_BYTES = OFF_WPOS + sizeof(uint16_t) * NW * BINS;
 };
 
 // Where a tile's elements come from and go to.

@@ -3,6 +3,8 @@
 // without gtest on top of the facade headers, plus the cases the reference cannot run:
 //   --host     run the sorts on an Adl TYPE_HOST device (BASELINE config #1: the CPU path; the shipped test
 //              hard-codes TYPE_CL, UnitTest/main.cpp:98)
+//   --gpus G   additionally run Demo.ShardedSort: G shards on G devices through Tahoe::ShardedSort (one process, RCCL
+//              exchange), checked against std::sort / std::stable_sort of the concatenated shards
 //   default    TYPE_CL = the MI355X HIP back-end; Demo.Scan includes 1024K, where the reference gives up
 //              (README.md:73-74, Pprims.cpp:134-138)
 // The ground truth is computed here with the C++ standard library (std::sort / std::stable_sort / running
@@ -18,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <Tahoe/ParallelPrimitives/ShardedSort.h>
 #include <vector>
 
 using namespace adl;
@@ -184,12 +187,81 @@ void demoFillCopy(Device* d, Pprims& p)
     printf("[       %s ] Demo.FillCopy (%.0f ms)\n", g_failed > before ? "FAIL" : "OK", now_ms() - t0);
 }
 
+// Demo.ShardedSort: G shards of the reference's random data (one srand seed per shard), keys and {key, value} pairs,
+// sorted across G devices; every rank's slice is downloaded and the concatenation compared with the host's sort.
+void demoShardedSort(int G)
+{
+    printf("[ RUN      ] Demo.ShardedSort (%d device%s)\n", G, G == 1 ? "" : "s");
+    const double t0 = now_ms();
+    const int before = g_failed;
+    {
+        ShardedSort s(G);
+        if (adl_assert_failures() == 0) {
+            for (int n = 1024; n <= 1024 * 1024; n *= 32) {
+                std::vector<Buffer<u32>*> in(G), out(G);
+                std::vector<Buffer<uint2>*> kin(G), kout(G);
+                std::vector<size_t> nIn(G), nOut(G), knOut(G);
+                std::vector<u32> all;
+                std::vector<SortData> kall;
+                for (int r = 0; r < G; ++r) {
+                    srand(123u + (unsigned)r);
+                    const int m = n + 13 * r;                       // ragged shards
+                    std::vector<u32> k(m);
+                    std::vector<SortData> kv(m);
+                    for (int i = 0; i < m; ++i) {
+                        k[i] = demoRandom<u32>(0u, 0xffffffffu) >> (r & 1 ? 3 : 0);   // odd ranks skewed low
+                        kv[i].m_key = k[i] & 0xfff000ffu;
+                        kv[i].m_value = (u32)(all.size() + i);
+                    }
+                    nIn[r] = (size_t)m;
+                    in[r] = new Buffer<u32>(s.getDevice(r), m);
+                    out[r] = new Buffer<u32>(s.getDevice(r), (u64)2 * G * (n + 13 * G));
+                    kin[r] = new Buffer<uint2>(s.getDevice(r), m);
+                    kout[r] = new Buffer<uint2>(s.getDevice(r), (u64)2 * G * (n + 13 * G));
+                    in[r]->write(&k[0], m);
+                    kin[r]->write((const uint2*)&kv[0], m);
+                    all.insert(all.end(), k.begin(), k.end());
+                    kall.insert(kall.end(), kv.begin(), kv.end());
+                }
+                s.waitForCompletion();
+                s.radixSort(&in[0], &nIn[0], &out[0], &nOut[0]);
+                s.radixSort(&kin[0], &nIn[0], &kout[0], &knOut[0]);
+                s.waitForCompletion();
+                std::vector<u32> got;
+                std::vector<SortData> kgot;
+                for (int r = 0; r < G; ++r) {
+                    std::vector<u32> part(nOut[r] ? nOut[r] : 1);
+                    std::vector<SortData> kpart(knOut[r] ? knOut[r] : 1);
+                    if (nOut[r]) out[r]->read(&part[0], (int)nOut[r]);
+                    if (knOut[r]) kout[r]->read((uint2*)&kpart[0], (int)knOut[r]);
+                    s.waitForCompletion();
+                    got.insert(got.end(), part.begin(), part.begin() + nOut[r]);
+                    kgot.insert(kgot.end(), kpart.begin(), kpart.begin() + knOut[r]);
+                }
+                std::sort(all.begin(), all.end());
+                std::stable_sort(kall.begin(), kall.end(), [](const SortData& a, const SortData& b) { return a.m_key < b.m_key; });
+                check(got == all, "ShardedSort keys", n);
+                bool same = kgot.size() == kall.size();
+                for (size_t i = 0; same && i < kall.size(); ++i) same = kgot[i].m_key == kall[i].m_key && kgot[i].m_value == kall[i].m_value;
+                check(same, "ShardedSort key-value (stable)", n);
+                printf("test %.1fK per device x %d\n", n / 1024.f, G);
+                for (int r = 0; r < G; ++r) { delete in[r]; delete out[r]; delete kin[r]; delete kout[r]; }
+            }
+        }
+    }
+    printf("[       %s ] Demo.ShardedSort (%.0f ms)\n", g_failed + adl_assert_failures() > before ? "FAIL" : "OK", now_ms() - t0);
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
 {
     bool host = false;
-    for (int i = 1; i < argc; ++i) host |= !strcmp(argv[i], "--host");
+    int gpus = 0;
+    for (int i = 1; i < argc; ++i) {
+        host |= !strcmp(argv[i], "--host");
+        if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
+    }
 
     DeviceUtils::Config cfg;
     cfg.m_type = host ? DeviceUtils::Config::DEVICE_CPU : DeviceUtils::Config::DEVICE_GPU;
@@ -209,6 +281,7 @@ int main(int argc, char** argv)
         if (!host) demoScan(d, p);   // scan has no host path in the reference either (Pprims.cpp:124-127)
     }
     DeviceUtils::deallocate(d);
+    if (!host && gpus > 0) demoShardedSort(gpus);
     g_failed += adl_assert_failures();
     printf("%s: %d failed checks\n", g_failed ? "FAILED" : "PASSED", g_failed);
     return g_failed;

@@ -79,3 +79,14 @@ def test_reference_unit_test_passes_on_mi355x_through_the_facade():
     tail = r.stdout[-1500:] + r.stderr[-1500:]
     assert r.returncode == 0, tail
     assert "[  PASSED  ] 3 tests" in r.stdout, tail
+
+
+@pytest.mark.gpu
+def test_demo_sharded_sort_through_the_facade_one_device(built):
+    """tests/demo/demo --gpus 1: Tahoe::ShardedSort (C++ facade over adlhip_group_* / adlhip_sharded_sort_*) with a
+    group of one device -- partition, splitters, RCCL self-exchange, local sort -- checked against std::sort /
+    std::stable_sort inside the binary."""
+    r = subprocess.run([DEMO, "--gpus", "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert re.search(r"OK \] Demo\.ShardedSort", r.stdout), r.stdout[-2000:]
+    assert "PASSED: 0 failed checks" in r.stdout

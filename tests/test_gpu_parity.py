@@ -863,8 +863,8 @@ def _segment_sort_expected(arr, starts, low_bits):
     return arr[order]
 
 
-@pytest.mark.parametrize("kind,cap", [(0, 4096), (0, 8192), (0, 16384), (1, 4096), (1, 8192)],
-                         ids=["u32-4Ki", "u32-8Ki", "u32-16Ki", "kv-4Ki", "kv-8Ki"])
+@pytest.mark.parametrize("kind,cap", [(0, 1536), (0, 2560), (0, 4096), (0, 8192), (0, 16384), (1, 1280), (1, 4096), (1, 8192)],
+                         ids=["u32-wave1536", "u32-wave2560", "u32-4Ki", "u32-8Ki", "u32-16Ki", "kv-wave1280", "kv-4Ki", "kv-8Ki"])
 def test_segment_sort_in_lds(dev, kind, cap):
     lib = _lib.load()
     rng = np.random.RandomState(cap + kind)
