@@ -81,6 +81,8 @@ struct adlhip_device {
     int tile_variant = -1;    // index into kVariants; -1 = best known per element size
     int rank_mode = 1;        // 1 = lane-ordered DS atomic ranking (needs lds_ordered), 0 = ballot match
     int lds_ordered = 0;      // result of the device self-test at creation
+    int mid_path = 1;         // 16 Ki < n <= 2 Mi: MSD pass + LDS finish (three launches) instead of per-digit passes
+    int mid_skip = 0;         // eligible sorts still to be sent down the per-digit passes after a skewed input (see mid_eligible)
     // profiling
     std::vector<PendingProf> pending;
     std::vector<hipEvent_t> event_pool;
@@ -96,6 +98,7 @@ struct adlhip_device {
     uint32_t* d_fault = nullptr;
     uint32_t* h_fault = nullptr;   // pinned: [0..1] filled by adlhip_sync, [4] by the last adlhip_fault_check snapshot
     hipEvent_t fault_snap = nullptr;   // recorded behind the last snapshot copy; null = none pending
+    uint32_t* d_mid_hist = nullptr;    // [16][4][256] slice histograms of the mid-size sort: zero between sorts
 };
 
 namespace {
@@ -486,7 +489,7 @@ OnesweepLayout onesweep_layout(const adlhip_device* d, size_t n, int max_passes,
 
 template <typename Buf, int NBITS, int NT, int K, int RANK>
 int launch_onesweep(adlhip_device* d, const Buf& src, const Buf& dst, const adlhip::PassTable* table, uint32_t* status,
-                    uint32_t* tickets, size_t n, int start_bit)
+                    uint32_t* tickets, size_t n, int start_bit, const uint32_t* dyn_start_bit = nullptr)
 {
     if (Buf::kSoa && !((NT == 256 && K == 16) || (NT == 1024 && K == 16))) return fail("internal: SoA tile");
     typedef typename Buf::IO IO;
@@ -499,7 +502,7 @@ int launch_onesweep(adlhip_device* d, const Buf& src, const Buf& dst, const adlh
     const IO io = Buf::io(src, dst);
     return launch(d, kernel_name<Buf, NBITS>("onesweep"), [&] {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), C::LDS_BYTES, d->stream, io, table, status, status_bytes, tickets,
-                           d->d_fault, (uint32_t)n, start_bit);
+                           d->d_fault, (uint32_t)n, start_bit, dyn_start_bit);
     });
 }
 
@@ -631,6 +634,132 @@ int small_sort(adlhip_device* d, E* data, size_t n, const std::vector<PassPlan>&
     return d->rank_mode ? launch_small<E, 1024, 16, 1>(d, data, n, sp) : launch_small<E, 1024, 16, 0>(d, data, n, sp);
 }
 
+// ---- segments finished in LDS (adlhip_segment_sort; pass 3 of the mid-size sort) -----------------------------------
+template <typename E, int NT, int K, int LBITS>
+int launch_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* seg_start, size_t num_segments, int low_bits,
+                        const uint32_t* dyn)
+{
+    auto kern = adlhip::segment_sort_kernel<E, NT, K, LBITS>;
+    const size_t own = sizeof(E) * NT * K + (size_t)(NT / 64) * (1u << LBITS) * 6 + 64;
+    const size_t lds = std::max(own, (size_t)adlhip::TileCfg<E, 8, NT, K>::LDS_BYTES);   // the through-memory path's carve
+    if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
+    // as many workgroups as are resident at once (LDS- or wave-limited), each loops over segments
+    const size_t per_cu = std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)32 / (NT / 64)));
+    const uint32_t grid = (uint32_t)std::min<size_t>(num_segments, per_cu * (size_t)d->prop.multiProcessorCount);
+    return launch(d, sizeof(E) == 4 ? "segment_sort_u32" : "segment_sort_e64", [&] {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, d->stream, in, out, seg_start, (uint32_t)num_segments, (uint32_t)low_bits,
+                           dyn, (const uint32_t*)nullptr, 0u, d->d_fault);
+    });
+}
+
+// largest segment the finishing kernel takes for this element size and number of low bits
+size_t segment_capacity(size_t elem_bytes, int low_bits)
+{
+    if (elem_bytes == 4) return low_bits <= 24 ? 16384 : 8192;
+    return low_bits <= 24 ? 8192 : 4096;
+}
+
+template <typename E>
+int segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* seg_start, size_t num_segments, size_t max_segment,
+                 int low_bits, const uint32_t* dyn)
+{
+    // tile by the caller's bound on the segment size; the digit width of the local passes by what fits beside the tile
+    if (sizeof(E) == 4) {
+        if (max_segment <= 4096) return launch_segment_sort<E, 256, 16, 9>(d, in, out, seg_start, num_segments, low_bits, dyn);
+        if (max_segment <= 8192) return launch_segment_sort<E, 512, 16, 9>(d, in, out, seg_start, num_segments, low_bits, dyn);
+        if (max_segment <= 16384 && low_bits <= 24) return launch_segment_sort<E, 512, 32, 8>(d, in, out, seg_start, num_segments, low_bits, dyn);
+    } else {
+        if (max_segment <= 4096) return launch_segment_sort<E, 256, 16, 9>(d, in, out, seg_start, num_segments, low_bits, dyn);
+        if (max_segment <= 8192 && low_bits <= 24) return launch_segment_sort<E, 512, 16, 8>(d, in, out, seg_start, num_segments, low_bits, dyn);
+    }
+    return fail("segment sort: segments of up to %zu elements with %d key bits exceed the LDS tile (%zu)", max_segment, low_bits,
+                segment_capacity(sizeof(E), low_bits));
+}
+
+// ---- mid-size sort: byte histograms + tables -> one MSD pass -> buckets finished in LDS (hybrid_kernels.hpp) ----------
+constexpr size_t kMidMaxU32 = size_t(2) << 20;
+constexpr size_t kMidMaxE64 = size_t(1) << 20;
+constexpr uint32_t kMidTile = 4096;   // pass 2 runs on 256 x 16 tiles
+
+struct MidLayout {
+    size_t off_tickets, off_table, off_seg, off_dyn, off_status, off_coop, total;
+    uint32_t wgs, rows, coop_wgs;
+};
+
+MidLayout mid_layout(size_t n)
+{
+    MidLayout L;
+    L.wgs = (uint32_t)((n + adlhip::kMidChunk - 1) / adlhip::kMidChunk);
+    L.rows = (uint32_t)((n + kMidTile - 1) / kMidTile) + adlhip::kChains + 1;
+    L.off_tickets = 0;
+    L.off_table = (size_t)adlhip::kChains * adlhip::kTicketStride * 4;
+    L.off_seg = L.off_table + sizeof(adlhip::PassTable);
+    L.off_dyn = align_up(L.off_seg + 257 * 4, 16);
+    L.off_status = align_up(L.off_dyn + sizeof(adlhip::MidDyn), 256);
+    // cooperative LSD kernel (safety net for skewed keys): bucket-major table [256][wgs] + 256 totals
+    L.coop_wgs = std::min<uint32_t>(256u, (uint32_t)((n + kMidTile - 1) / kMidTile));
+    L.off_coop = align_up(L.off_status + (size_t)L.rows * 256 * 4, 256);
+    L.total = L.off_coop + (size_t)256 * L.coop_wgs * 4 + 256 * 4;
+    return L;
+}
+
+bool mid_eligible(adlhip_device* d, size_t elem_bytes, size_t n, int sort_bits, int max_bits)
+{
+    if (!(d->sort_algo < 0 && d->mid_path && max_bits == 32 && sort_bits == 32 && d->rank_mode == 1 && d->digit_bits == 8 &&
+          d->tile_variant < 0 && n > kSmallMax && n <= (elem_bytes == 4 ? kMidMaxU32 : kMidMaxE64)))
+        return false;
+    // Skewed keys make the mid-size sort fall back to its cooperative LSD kernel, 3-5x the cost of the per-digit passes
+    // (profiles/r2_mid_size_distributions.txt).  mid_prep_kernel reports each sort's mode into pinned memory; the host looks
+    // at the most recent report WITHOUT synchronising (it may be a sort or two old) and, after a fallback, sends the next
+    // eight eligible sorts of this handle down the per-digit passes before it tries again.  Only speed depends on this.
+    if (d->mid_skip > 0) {
+        --d->mid_skip;
+        return false;
+    }
+    if (d->h_fault[9] == 2u) {
+        d->h_fault[9] = 0u;
+        d->mid_skip = 8;
+        return false;
+    }
+    return true;
+}
+
+template <typename E>
+int mid_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
+{
+    const MidLayout L = mid_layout(n);
+    char* wb = reinterpret_cast<char*>(work);
+    uint32_t* tickets = reinterpret_cast<uint32_t*>(wb + L.off_tickets);
+    adlhip::PassTable* table = reinterpret_cast<adlhip::PassTable*>(wb + L.off_table);
+    uint32_t* seg_start = reinterpret_cast<uint32_t*>(wb + L.off_seg);
+    adlhip::MidDyn* dyn = reinterpret_cast<adlhip::MidDyn*>(wb + L.off_dyn);
+    uint32_t* status = reinterpret_cast<uint32_t*>(wb + L.off_status);
+    const uint32_t status_vecs = (uint32_t)((size_t)L.rows * 256 * 4 / 16);
+    // buckets average n / 256 elements; the LDS tile of pass 3 holds at least twice that, and an input whose largest
+    // bucket still does not fit goes to the cooperative LSD kernel instead (decided on the device by mid_prep_kernel)
+    const size_t cap = std::min(std::max<size_t>(4096, 2 * ((n + 255) / 256)), segment_capacity(sizeof(E), 24));
+    int rc = launch(d, sizeof(E) == 4 ? "mid_prep_u32" : "mid_prep_e64", [&] {
+        hipLaunchKernelGGL((adlhip::mid_prep_kernel<E>), dim3(L.wgs), dim3(adlhip::kMidPrepNT), 0, d->stream, (const E*)data, (uint32_t)n,
+                           kMidTile, d->d_mid_hist, table, seg_start, dyn, reinterpret_cast<adlhip::u32x4*>(tickets),
+                           reinterpret_cast<adlhip::u32x4*>(status), status_vecs, d->d_fault + 12, d->d_fault, (uint32_t)cap,
+                           d->h_fault + 9);
+    });
+    if (rc) return rc;
+    rc = launch_onesweep<AosBuf<E>, 8, 256, 16, 1>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, table, status, tickets, n, 24, &dyn->start_bit);
+    if (rc) return rc;
+    rc = segment_sort<E>(d, tmp, data, seg_start, 256, cap, 24, &dyn->start_bit);
+    if (rc) return rc;
+    // the safety net: returns at once unless mid_prep_kernel found a bucket beyond `cap`
+    using CC = adlhip::TileCfg<E, 8, 256, 16>;
+    auto coop = adlhip::coop_lsd_sort_kernel<E, 256, 16>;
+    if (ensure_lds(coop, CC::LDS_BYTES)) return ADLHIP_FAILURE;
+    uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
+    return launch(d, sizeof(E) == 4 ? "mid_coop_lsd_u32" : "mid_coop_lsd_e64", [&] {
+        hipLaunchKernelGGL(coop, dim3(L.coop_wgs), dim3(256), CC::LDS_BYTES, d->stream, data, tmp, (uint32_t)n, ctable,
+                           ctable + (size_t)256 * L.coop_wgs, d->d_fault + 13, (const uint32_t*)&dyn->start_bit, d->d_fault);
+    });
+}
+
 size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)
 {
     const size_t a = work_bytes_three_kernel(d, n);
@@ -638,7 +767,8 @@ size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)
     if (elem_kind == ADLHIP_ELEM_U32) b = onesweep_layout(d, n, max_passes_for(d, 32), buf_tile<AosBuf<uint32_t>>(d, n)).total;
     else if (elem_kind == ADLHIP_ELEM_SOA32) b = onesweep_layout(d, n, max_passes_for(d, 64), buf_tile<SoaBuf>(d, n)).total;
     else b = onesweep_layout(d, n, max_passes_for(d, 64), buf_tile<AosBuf<uint64_t>>(d, n)).total;   // as onesweep_sort<Buf>()
-    return std::max(a, b);
+    const size_t c = n <= kMidMaxU32 ? mid_layout(n).total : mid_layout(kMidMaxU32).total;   // mid-size sort (monotone in n)
+    return std::max(std::max(a, b), c);
 }
 
 // Work bytes that suffice for EVERY n' <= n with the current knobs: the requirement of one n is not monotone (a smaller
@@ -694,74 +824,8 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
     if (n == 0) return ADLHIP_SUCCESS;
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
     if (d->sort_algo < 0 && n <= kSmallMax) return small_sort<E>(d, data, n, plan);   // one workgroup, one launch
+    if (mid_eligible(d, sizeof(E), n, sort_bits, max_bits)) return mid_sort<E>(d, data, tmp, work, n);   // three launches
     return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, n, plan);
-}
-
-// ---- segments finished in LDS (pass C of the hybrid sort; also a primitive of its own) ----------------------
-template <typename E, int NT, int K, int LBITS>
-int launch_segment_sort(adlhip_device* d, E* data, const uint32_t* seg_start, size_t num_segments, int low_bits,
-                        const uint32_t* gate, uint32_t gate_value)
-{
-    auto kern = adlhip::segment_sort_kernel<E, NT, K, LBITS>;
-    const size_t lds = sizeof(E) * NT * K + (size_t)(NT / 64) * (1u << LBITS) * 4 + 128;
-    if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
-    // persistent workgroups: as many as are resident at once (LDS- or wave-limited), each loops over segments
-    size_t per_cu = std::min<size_t>((size_t)160 * 1024 / lds, (size_t)32 / (NT / 64));
-    if (const char* o = getenv("ADLHIP_SEGSORT_WGS_PER_CU")) per_cu = std::max(1, atoi(o));
-    const uint32_t grid = (uint32_t)std::min<size_t>(num_segments, per_cu * (size_t)d->prop.multiProcessorCount);
-    return launch(d, sizeof(E) == 4 ? "segment_sort_u32" : "segment_sort_e64", [&] {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, d->stream, data, seg_start, (uint32_t)num_segments, (uint32_t)low_bits,
-                           gate, gate_value, d->d_fault);
-    });
-}
-
-template <typename E, int K, int LBITS>
-int launch_segment_sort_wave(adlhip_device* d, E* data, const uint32_t* seg_start, size_t num_segments, int low_bits,
-                             const uint32_t* gate, uint32_t gate_value)
-{
-    constexpr int WAVES = 4;
-    auto kern = adlhip::segment_sort_wave_kernel<E, K, LBITS, WAVES>;
-    const size_t lds = (size_t)WAVES * (sizeof(E) * 64 * K + (size_t)(1u << LBITS) * 4);
-    if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
-    const uint32_t grid = (uint32_t)((num_segments + WAVES - 1) / WAVES);
-    return launch(d, sizeof(E) == 4 ? "segment_sort_wave_u32" : "segment_sort_wave_e64", [&] {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, d->stream, data, seg_start, (uint32_t)num_segments,
-                           (uint32_t)low_bits, gate, gate_value, d->d_fault);
-    });
-}
-
-// largest segment the finishing kernel takes for this element size and number of low bits (0: none)
-size_t segment_capacity(size_t elem_bytes, int low_bits)
-{
-    if (elem_bytes == 4) return low_bits <= 24 ? 16384 : 8192;
-    return low_bits <= 24 ? 8192 : 4096;
-}
-
-template <typename E>
-int segment_sort(adlhip_device* d, E* data, const uint32_t* seg_start, size_t num_segments, size_t max_segment, int low_bits,
-                 const uint32_t* gate, uint32_t gate_value)
-{
-    // segments that fit one wave's registers: a wave per segment, no workgroup barriers (low_bits <= 18: two passes)
-    static const bool no_wave = getenv("ADLHIP_SEGSORT_NO_WAVE") != nullptr;
-    if (!no_wave && low_bits <= 18) {
-        if (sizeof(E) == 4) {
-            if (max_segment <= 1536) return launch_segment_sort_wave<E, 24, 9>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
-            if (max_segment <= 2560) return launch_segment_sort_wave<E, 40, 9>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
-        } else {
-            if (max_segment <= 1280) return launch_segment_sort_wave<E, 20, 9>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
-        }
-    }
-    // tile by the caller's bound on the segment size; the digit width of the local passes by what fits beside the tile
-    if (sizeof(E) == 4) {
-        if (max_segment <= 4096) return launch_segment_sort<E, 256, 16, 9>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
-        if (max_segment <= 8192) return launch_segment_sort<E, 512, 16, 9>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
-        if (max_segment <= 16384 && low_bits <= 24) return launch_segment_sort<E, 512, 32, 8>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
-    } else {
-        if (max_segment <= 4096) return launch_segment_sort<E, 256, 16, 9>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
-        if (max_segment <= 8192 && low_bits <= 24) return launch_segment_sort<E, 512, 16, 8>(d, data, seg_start, num_segments, low_bits, gate, gate_value);
-    }
-    return fail("segment sort: segments of up to %zu elements with %d key bits exceed the LDS tile (%zu)", max_segment, low_bits,
-                segment_capacity(sizeof(E), low_bits));
 }
 
 // ---- MSB partition (multi-GPU send side) -----------------------------------------------------------
@@ -915,6 +979,14 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         return fail("cannot allocate the fault word");
     }
     memset(d->h_fault, 0, 64);
+    if (hipMalloc(&d->d_mid_hist, 16 * 1024 * 4) != hipSuccess || hipMemsetAsync(d->d_mid_hist, 0, 16 * 1024 * 4, d->stream) != hipSuccess) {
+        if (d->d_mid_hist) hipFree(d->d_mid_hist);
+        hipFree(d->d_fault);
+        hipHostFree(d->h_fault);
+        if (own && d->stream) hipStreamDestroy(d->stream);
+        delete d;
+        return fail("cannot allocate the mid-size sort's histogram area");
+    }
     {   // self-test: are returning DS atomics lane-ordered on this device?  (enables "sort.rank" = 1)
         uint32_t mism = 1;
         d->lds_ordered = (run_lds_order_selftest(d, 64, &mism) == ADLHIP_SUCCESS && mism == 0) ? 1 : 0;
@@ -923,6 +995,7 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
     if (const char* a = getenv("ADLHIP_SORT_ALGO")) { int v = atoi(a); if (v >= -1 && v <= 1) d->sort_algo = v; }
     if (const char* t = getenv("ADLHIP_SORT_TILE")) { int v = atoi(t); if (v >= -1 && v < kNumVariants) d->tile_variant = v; }
     if (const char* r = getenv("ADLHIP_SORT_RANK")) d->rank_mode = (atoi(r) && d->lds_ordered) ? 1 : 0;
+    if (const char* m = getenv("ADLHIP_SORT_MID")) d->mid_path = atoi(m) ? 1 : 0;
     if (const char* b = getenv("ADLHIP_DIGIT_BITS")) { int v = atoi(b); d->digit_bits = (v == 4 || v == 7) ? v : 8; }
     *out = d;
     return ADLHIP_SUCCESS;
@@ -947,6 +1020,7 @@ int adlhip_device_destroy(adlhip_device* d)
     for (auto& p : d->pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
     for (auto e : d->event_pool) hipEventDestroy(e);
     if (d->fault_snap) hipEventDestroy(d->fault_snap);
+    hipFree(d->d_mid_hist);
     hipFree(d->d_fault);
     hipHostFree(d->h_fault);
     if (d->own_stream) hipStreamDestroy(d->stream);
@@ -1239,8 +1313,10 @@ int adlhip_segment_sort(adlhip_device* d, int elem_kind, void* data, const uint3
     if (num_segments > 0x7fffffffull) return fail("segment sort: too many segments");
     if (!d->lds_ordered) return fail("segment sort needs lane-ordered DS atomics; the device self-test failed");
     if (elem_kind == ADLHIP_ELEM_U32)
-        return segment_sort<uint32_t>(d, static_cast<uint32_t*>(data), seg_start, num_segments, max_segment, low_bits, nullptr, 0u);
-    return segment_sort<uint64_t>(d, static_cast<uint64_t*>(data), seg_start, num_segments, max_segment, low_bits, nullptr, 0u);
+        return segment_sort<uint32_t>(d, static_cast<const uint32_t*>(data), static_cast<uint32_t*>(data), seg_start, num_segments,
+                                      max_segment, low_bits, nullptr);
+    return segment_sort<uint64_t>(d, static_cast<const uint64_t*>(data), static_cast<uint64_t*>(data), seg_start, num_segments,
+                                  max_segment, low_bits, nullptr);
 }
 
 // ---- scan ---------------------------------------------------------------------------------------
@@ -1353,6 +1429,9 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
         if (value < -1 || value >= kNumVariants) return fail("sort.tile must be in [-1,%d)", kNumVariants);
         d->tile_variant = value;
 
+    } else if (!strcmp(name, "sort.mid")) {
+        if (value != 0 && value != 1) return fail("sort.mid must be 0 or 1");
+        d->mid_path = value;
     } else if (!strcmp(name, "sort.rank")) {
         if (value != 0 && value != 1) return fail("sort.rank must be 0 or 1");
         if (value == 1 && !d->lds_ordered) return fail("sort.rank = 1 needs lane-ordered DS atomics; the device self-test failed");
@@ -1374,6 +1453,7 @@ int adlhip_get_param(adlhip_device* d, const char* name, int* value)
     else if (!strcmp(name, "sort.digit_bits")) *value = d->digit_bits;
     else if (!strcmp(name, "sort.tile")) *value = d->tile_variant;
     else if (!strcmp(name, "sort.rank")) *value = d->rank_mode;
+    else if (!strcmp(name, "sort.mid")) *value = d->mid_path;
     else if (!strcmp(name, "sort.lds_ordered")) *value = d->lds_ordered;
     else if (!strcmp(name, "profile")) *value = d->profile;
     else return fail("unknown parameter '%s'", name);

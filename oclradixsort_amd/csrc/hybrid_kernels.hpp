@@ -1,20 +1,16 @@
-// hybrid_kernels.hpp -- "sort.algo" = 2: two MSD one-sweep passes + one LDS-resident finish, for 32-bit keys.
+// hybrid_kernels.hpp -- MSD pass + LDS-resident finish: the segment sort primitive (adlhip_segment_sort) and the
+// mid-size sort built on it.
 //
 // The LSD sort of Pprims::radixSort (Tahoe/ParallelPrimitives/Pprims.cpp:304-406) moves every element through
-// global memory once per digit.  A pass of this library costs ~120 us at 64 Mi keys whatever its digit width
-// (profiles/r2_pass_time_vs_digit_width.txt), so the lever left is the NUMBER of global passes:
-//   A  one-sweep pass on the TOP 7 bits of the sorted range        (128 buckets)
-//   B  one-sweep pass on the next 7 bits, bucket by bucket          (16384 segments of n / 16384 elements)
-//   C  every segment is loaded into LDS once, finished there on the remaining <= 18 bits (two local passes
-//      of <= 9 bits) and written back in place, fully coalesced.
-// 3 sweeps + one histogram read instead of 4 + 1.  The result is the same array any stable sort produces
-// (total order + stability => unique output), so parity with the reference's CPU sort
-// (Tahoe/Algorithm/Sort/RadixSort.cpp:10-104) is unaffected.
+// global memory once per digit and costs one to three dependent kernel launches per digit.  Between 16 Ki and
+// 2 Mi keys -- every size of the reference's own test, UnitTest/main.cpp:105 -- those launches, not the bytes, are
+// the cost.  One MSD pass on the most significant byte that varies + one kernel that finishes every bucket in
+// LDS need three launches in all.  The result is the array any stable sort produces (total order + stability =>
+// unique output), so parity with the reference's CPU sort (Tahoe/Algorithm/Sort/RadixSort.cpp:10-104) is unaffected.
 //
-// What makes it safe for ANY input: the one up-front histogram (14 bits, ONE LDS atomic per key) yields every
-// segment's size before anything is moved; if a segment would not fit the finishing kernel's LDS tile the
-// tables kernel raises a device-side mode word and the classic LSD passes run instead (their launches are
-// always enqueued; each kernel of the path not taken returns at its first instruction).
+// Measured and NOT built on this (profiles/r2_segment_sort_*.txt): the same structure for 64 Mi keys (two MSD passes
+// of 7 bits + finish on 18 bits).  The finishing kernel is bound by its LDS traffic and barriers (250-320 us for
+// 64 Mi keys, workgroup- or wave-per-segment alike), more than the one global pass it would save.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,263 +29,442 @@ constexpr uint32_t kModeHybrid = 0u;            // mode word values (work buffer
 constexpr uint32_t kModeClassic = 1u;
 
 // ------------------------------------------------------------------------------------------
-// C: finish segments in LDS.  A workgroup takes segments blockIdx.x, blockIdx.x + gridDim.x, ... (the grid is
-// sized to the resident slots: a workgroup per segment spent a fifth of its life being launched, and nothing
-// was loading while a workgroup sorted).  The segment [seg_start[s], seg_start[s+1]) holds at most NT*K elements
-// (guaranteed by the mode word; checked again here).  `low_bits` (1..3*LBITS) bits starting at bit 0 are sorted
-// with up to three stable local passes of at most LBITS bits: per-wave returning DS atomics give the in-wave
-// rank (radix_kernels.hpp rank_in_wave has the argument for why that is the stable rank), the per-wave counts
-// are folded and scanned by the threads that own the bins, elements go to LDS at their sorted position.  The
-// last pass leaves the tile in LDS and the workgroup writes it back over the segment, consecutive threads to
-// consecutive addresses.  In place: everything of a segment was read before its first store.
-// Software pipeline: the keys of the NEXT segment are requested before the local passes of the current one
-// (they land in registers while the workgroup sorts; vmcnt retires in order and these loads are older than the
-// current segment's stores, so consuming them never waits for a store), its bounds one segment earlier still.
-// Slots beyond the segment's size take no part (no pad keys: hundreds of pads on one LDS counter serialise).
+// C: finish segments in LDS.  A workgroup takes segments blockIdx.x, blockIdx.x + gridDim.x, ...  The segment
+// [seg_start[s], seg_start[s+1]) of `in` is loaded once, sorted on its low `low_bits` bits with up to three stable
+// local passes of at most LBITS bits, and written to the same range of `out` (in == out: in place; everything of a
+// segment is read before its first store).  Per local pass and wave: returning DS atomics on the wave's own counters
+// give the in-wave rank (radix_kernels.hpp rank_in_wave has the argument for why that is the stable rank); after ONE
+// barrier every wave folds the counts of all waves for its lanes' bins, DPP-scans the bin totals and writes the tile
+// positions of its own (wave, bin) runs -- 16-bit, read by that wave only, so no second barrier -- and scatters its
+// elements to LDS; after a second barrier the tile is read back in order.  Two barriers per pass (the first version
+// had seven and spent most of a segment's ~20K cycles in them).  Slots beyond the segment's size take no part (no
+// pad keys: hundreds of pads on one LDS counter serialise).
+// A segment of more than NT*K elements cannot live in the tile.  With a partner array (`in` != `out`) the workgroup
+// sorts it through global memory instead -- count, scan, tile-by-tile scatter with a per-digit carry, 8 bits at a
+// time, ping-ponging between the segment's ranges of the two arrays (slow: one workgroup; it exists so that skewed
+// inputs stay correct, and the host keeps such inputs rare).  In place there is no partner: the segment is left as
+// it is and the device fault word is raised.
+// dyn (may be null): dyn[1] overrides low_bits -- the mid-size sort chooses its digit positions on the device -- and a
+// non-zero dyn[2] makes the kernel return at once (MidDyn::mode).
 // ------------------------------------------------------------------------------------------
 template <typename E, int NT, int K, int LBITS>
-__global__ __launch_bounds__(NT) void segment_sort_kernel(E* data, const uint32_t* __restrict__ seg_start,
-                                                          uint32_t num_segments, uint32_t low_bits,
+__global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, const uint32_t* __restrict__ seg_start,
+                                                          uint32_t num_segments, uint32_t low_bits_arg,
+                                                          const uint32_t* __restrict__ dyn,
                                                           const uint32_t* __restrict__ gate, uint32_t gate_value,
                                                           uint32_t* fault)
 {
     if (gate && *gate != gate_value) return;
+    if (dyn && dyn[2] != 0u) return;                   // mid-size sort: the cooperative LSD kernel takes this input
     constexpr int NW = NT / 64;
     constexpr int CAP = NT * K;
     constexpr int BINS = 1 << LBITS;
-    constexpr int BPT = (BINS + NT - 1) / NT;          // bins per bookkeeping thread (2 at 256 threads, else 1)
-    constexpr int BK_THREADS = BINS / BPT;
+    constexpr int BPL = BINS / 64;                     // bins per lane when a wave folds and scans the counts
+    static_assert(BPL == 4 || BPL == 8, "256 or 512 bins");
+    using F = TileCfg<E, 8, NT, K>;                    // LDS carve of the through-memory path (sort_scatter_tile)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     E* __restrict__ s_elems = reinterpret_cast<E*>(smem);
-    uint32_t* __restrict__ s_wcnt = reinterpret_cast<uint32_t*>(smem + sizeof(E) * CAP);   // [NW][BINS]
-    uint32_t* __restrict__ s_wsum = s_wcnt + NW * BINS;
+    uint32_t* __restrict__ s_wcnt = reinterpret_cast<uint32_t*>(smem + sizeof(E) * CAP);            // [NW][BINS]
+    uint16_t* __restrict__ s_wpos = reinterpret_cast<uint16_t*>(s_wcnt + NW * BINS);                 // [NW][BINS]
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
     uint32_t* my_wcnt = s_wcnt + w * BINS;
-    const uint32_t stride = gridDim.x;
+    uint16_t* my_wpos = s_wpos + w * BINS;
+    const uint32_t low_bits = dyn ? dyn[1] : low_bits_arg;
+    const int npass = ((int)low_bits + LBITS - 1) / LBITS;   // digits as even as possible: 18 bits, LBITS 9 -> 9 + 9
 
-    // bounds of segment s (a segment beyond the tile is skipped and reported: never sorted wrongly in silence)
-    auto bounds = [&](uint32_t s, uint32_t& begin, uint32_t& m) {
-        begin = 0u;
-        m = 0u;
-        if (s < num_segments) {
-            begin = seg_start[s];
-            m = seg_start[s + 1] - begin;
-            if (m > (uint32_t)CAP) {
+    for (uint32_t seg = blockIdx.x; seg < num_segments; seg += gridDim.x) {
+        const uint32_t begin = seg_start[seg];
+        const uint32_t m = seg_start[seg + 1] - begin;
+        if (m == 0u) continue;
+        const E* src = in + begin;
+        E* dst = out + begin;
+        if (m > (uint32_t)CAP) {
+            if (in == out) {   // no partner array: never sort wrongly in silence
                 if (tid == 0) atomicOr(fault + 1, 0x40000u);   // sticky word
-                m = 0u;
+                continue;
             }
+            // ---- through global memory: 8-bit LSD passes by this one workgroup ------------------------------
+            if (low_bits & 7u) {   // the through-memory path sorts whole bytes (the mid-size sort's digits are)
+                if (tid == 0) atomicOr(fault + 1, 0x40000u);
+                continue;
+            }
+            const int nfp = (int)low_bits / 8;
+            const E* a = src;                      // pass input
+            E* b = dst;                            // pass output; the partner of `out`'s range is `in`'s
+            E* other = const_cast<E*>(src);
+            uint32_t* hist = reinterpret_cast<uint32_t*>(smem + F::OFF_WCNT);   // [NW][256]
+            uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + F::OFF_WSUM);
+            for (int p = 0; p < nfp; ++p) {
+                const int sb = 8 * p;
+                for (int i = tid; i < NW * 256; i += NT) hist[i] = 0u;
+                __syncthreads();
+                for (uint32_t i = (uint32_t)tid; i < m; i += (uint32_t)NT)
+                    atomicAdd(&hist[w * 256 + (((uint32_t)a[i] >> sb) & 255u)], 1u);
+                __syncthreads();
+                uint32_t cnt_b = 0u;
+                if (tid < 256)
+                    for (int i = 0; i < NW; ++i) cnt_b += hist[i * 256 + tid];
+                uint32_t carry = block_excl_scan_u32<NT>(cnt_b, s_wsum, nullptr);   // thread d: where digit d's run starts
+                const AosIO<E> io{a, b};
+                for (uint32_t base = 0; base < m; base += (uint32_t)CAP) {
+                    const uint32_t left = m - base;
+                    sort_scatter_tile<AosIO<E>, 8, NT, K, 1>(io, base, left < (uint32_t)CAP ? left : (uint32_t)CAP, m, sb, smem,
+                                                             [&](int, uint32_t c) { const uint32_t g = carry; carry += c; return g; });
+                }
+                // this pass's stores must be visible to the next pass's loads (same workgroup, other waves)
+                __threadfence_block();
+                __syncthreads();
+                a = b;
+                b = (b == dst) ? other : dst;
+            }
+            if (a != dst) {   // even number of passes: the result sits in the partner's range
+                for (uint32_t i = (uint32_t)tid; i < m; i += (uint32_t)NT) dst[i] = a[i];
+            }
+            __syncthreads();
+            continue;
         }
-    };
-    // wave-striped: with keff = ceil(m / NT) items per thread in use, wave w owns elements [w*64*keff, (w+1)*64*keff)
-    auto fetch = [&](E (&x)[K], uint32_t begin, uint32_t m) {
+        // ---- in LDS -------------------------------------------------------------------------------------------
+        // wave-striped: with keff = ceil(m / NT) items per thread in use, wave w owns elements [w*64*keff, (w+1)*64*keff)
         const int keff = (int)((m + (uint32_t)NT - 1u) / (uint32_t)NT);
         const uint32_t wbase = (uint32_t)(w * 64 * keff + lane);
-        const E* p = data + begin + wbase;
-        const int rem = (int)m - (int)wbase;
+        const int rem = (int)m - (int)wbase;          // item j of this lane exists iff j*64 < rem
+        int wave_valid = (int)m - w * 64 * keff;      // elements of this wave: a prefix in (item, lane) order
+        wave_valid = wave_valid < 0 ? 0 : (wave_valid > 64 * keff ? 64 * keff : wave_valid);
+        E e[K];
 #pragma unroll
         for (int j = 0; j < K; ++j)
-            if (j < keff) x[j] = (j * 64 < rem) ? p[j * 64] : E(0);
-    };
-
-    uint32_t seg = blockIdx.x;
-    uint32_t begin, m, nbegin, nm;
-    bounds(seg, begin, m);
-    bounds(seg + stride, nbegin, nm);
-    E e[K];
-    fetch(e, begin, m);
-
-    // digits as even as possible: low_bits = 18, LBITS = 9 -> 9 + 9; 18 with LBITS = 8 -> 6 + 6 + 6
-    const int npass = ((int)low_bits + LBITS - 1) / LBITS;
-    for (; seg < num_segments; seg += stride) {
-        uint32_t nnbegin, nnm;
-        bounds(seg + 2u * stride, nnbegin, nnm);
-        E en[K];
-        fetch(en, nbegin, nm);   // in flight during the local passes below
-        if (m != 0u) {
-            const int keff = (int)((m + (uint32_t)NT - 1u) / (uint32_t)NT);
-            const uint32_t wbase = (uint32_t)(w * 64 * keff + lane);
-            const int rem = (int)m - (int)wbase;          // item j of this lane exists iff j*64 < rem
-            int wave_valid = (int)m - w * 64 * keff;      // elements of this wave: a prefix in (item, lane) order
-            wave_valid = wave_valid < 0 ? 0 : (wave_valid > 64 * keff ? 64 * keff : wave_valid);
-            int sb = 0;
-            for (int p = 0; p < npass; ++p) {
-                const int nb = ((int)low_bits - sb + (npass - p - 1)) / (npass - p);
-                const uint32_t mask = (1u << nb) - 1u;
-                const int bins = 1 << nb;
-                auto digit = [&](E x) -> uint32_t { return ((uint32_t)x >> sb) & mask; };
-                for (int b = lane; b < bins; b += 64) my_wcnt[b] = 0u;
-                uint32_t rnk[K];
-                {
-                    // all elements of the wave in one bin (constant low bits): ranks are item*64 + lane
-                    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)digit(e[0]));
-                    bool same = true;
+            if (j < keff) e[j] = (j * 64 < rem) ? src[wbase + (uint32_t)(j * 64)] : E(0);
+        int sb = 0;
+        for (int p = 0; p < npass; ++p) {
+            const int nb = ((int)low_bits - sb + (npass - p - 1)) / (npass - p);
+            const uint32_t mask = (1u << nb) - 1u;
+            auto digit = [&](E x) -> uint32_t { return ((uint32_t)x >> sb) & mask; };
 #pragma unroll
-                    for (int j = 0; j < K; ++j)
-                        if (j < keff) same &= (j * 64 >= rem) | (digit(e[j]) == d0);
-                    if (__all(same)) {
-#pragma unroll
-                        for (int j = 0; j < K; ++j) rnk[j] = (uint32_t)(j * 64 + lane);
-                        if (lane == 0 && wave_valid > 0)
-                            __hip_atomic_store(&my_wcnt[d0], (uint32_t)wave_valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < K; ++j)
-                            if (j < keff && j * 64 < rem)
-                                rnk[j] = __hip_atomic_fetch_add(&my_wcnt[digit(e[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-                __syncthreads();
-                // bookkeeping threads: fold the per-wave counts of their bins, scan over bins, write tile positions back
-                uint32_t wc[NW][BPT];
-                uint32_t mine = 0u;
-                const bool bk = tid < BK_THREADS && tid * BPT < bins;
-                if (bk) {
-#pragma unroll
-                    for (int i = 0; i < NW; ++i)
-#pragma unroll
-                        for (int q = 0; q < BPT; ++q) {
-                            wc[i][q] = s_wcnt[i * BINS + tid * BPT + q];
-                            mine += wc[i][q];
-                        }
-                }
-                const uint32_t toff = block_excl_scan_u32<NT>(mine, s_wsum, nullptr);
-                if (bk) {
-                    uint32_t run = toff;
-#pragma unroll
-                    for (int q = 0; q < BPT; ++q)
-#pragma unroll
-                        for (int i = 0; i < NW; ++i) {
-                            s_wcnt[i * BINS + tid * BPT + q] = run;
-                            run += wc[i][q];
-                        }
-                }
-                __syncthreads();
+            for (int q = 0; q < BPL; ++q) my_wcnt[q * 64 + lane] = 0u;
+            uint32_t rnk[K];
+            {
+                // all elements of the wave in one bin (constant low bits): ranks are item*64 + lane
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)digit(e[0]));
+                bool same = true;
 #pragma unroll
                 for (int j = 0; j < K; ++j)
-                    if (j < keff && j * 64 < rem) s_elems[my_wcnt[digit(e[j])] + rnk[j]] = e[j];
-                __syncthreads();
-                if (p + 1 < npass) {
+                    if (j < keff) same &= (j * 64 >= rem) | (digit(e[j]) == d0);
+                if (__all(same)) {
+#pragma unroll
+                    for (int j = 0; j < K; ++j) rnk[j] = (uint32_t)(j * 64 + lane);
+                    if (lane == 0 && wave_valid > 0)
+                        __hip_atomic_store(&my_wcnt[d0], (uint32_t)wave_valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                } else {
 #pragma unroll
                     for (int j = 0; j < K; ++j)
-                        if (j < keff && j * 64 < rem) e[j] = s_elems[wbase + (uint32_t)(j * 64)];
-                    __syncthreads();
+                        if (j < keff && j * 64 < rem)
+                            rnk[j] = __hip_atomic_fetch_add(&my_wcnt[digit(e[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                sb += nb;
             }
-            E* out = data + begin;
-            for (uint32_t i = (uint32_t)tid; i < m; i += (uint32_t)NT) out[i] = s_elems[i];
-        }
+            __syncthreads();   // every wave's counts are final; the previous pass's read-back is done
+            {   // lane l owns bins [l*BPL, (l+1)*BPL): totals over all waves, the part of the waves before mine, tile positions
+                uint32_t tot[BPL], pre[BPL];
 #pragma unroll
-        for (int j = 0; j < K; ++j) e[j] = en[j];
-        begin = nbegin; m = nm;
-        nbegin = nnbegin; nm = nnm;
+                for (int q = 0; q < BPL; ++q) tot[q] = pre[q] = 0u;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+#pragma unroll
+                    for (int q = 0; q < BPL; q += 4) {
+                        const u32x4 r = *reinterpret_cast<const u32x4*>(s_wcnt + i * BINS + lane * BPL + q);
+                        tot[q] += r.x; tot[q + 1] += r.y; tot[q + 2] += r.z; tot[q + 3] += r.w;
+                        if (i < w) { pre[q] += r.x; pre[q + 1] += r.y; pre[q + 2] += r.z; pre[q + 3] += r.w; }
+                    }
+                }
+                uint32_t s = 0u;
+#pragma unroll
+                for (int q = 0; q < BPL; ++q) s += tot[q];
+                uint32_t run = wave_incl_scan_u32(s) - s;
+#pragma unroll
+                for (int q = 0; q < BPL; q += 2) {
+                    const uint32_t p0 = run + pre[q];
+                    run += tot[q];
+                    const uint32_t p1 = run + pre[q + 1];
+                    run += tot[q + 1];
+                    *reinterpret_cast<uint32_t*>(my_wpos + lane * BPL + q) = p0 | (p1 << 16);   // positions < CAP <= 65536
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if (j < keff && j * 64 < rem) s_elems[(uint32_t)my_wpos[digit(e[j])] + rnk[j]] = e[j];
+            __syncthreads();   // the tile is in sorted order
+            if (p + 1 < npass) {
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+                    if (j < keff && j * 64 < rem) e[j] = s_elems[wbase + (uint32_t)(j * 64)];
+            }
+            sb += nb;
+        }
+        if (npass == 0) {   // nothing left to sort: the segment only moves
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if (j < keff && j * 64 < rem) dst[wbase + (uint32_t)(j * 64)] = e[j];
+        } else {
+            for (uint32_t i = (uint32_t)tid; i < m; i += (uint32_t)NT) dst[i] = s_elems[i];
+        }
+        __syncthreads();   // the tile is free for the next segment
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// C, wave-sized segments: ONE WAVE per segment, no workgroup barrier anywhere.  A segment of at most 64*K
-// elements lives in the wave's registers (lane l, item j <-> element j*64 + l: every load and store instruction
-// moves 64 consecutive elements) and in the wave's private slice of LDS.  Per local pass: returning DS atomics on
-// the wave's own bins give the stable rank (issue order = item order, colliding lanes in lane order), the lanes
-// scan the bins (BINS / 64 per lane + one DPP scan), the elements go to LDS at bin start + rank and come back in
-// order.  DS operations of one wave execute in issue order, so the phases need no barrier -- which is what made
-// the workgroup-per-segment form slow (14 barriers per 4 Ki keys, ~20K cycles per segment).
+// Mid-size sort (16 Ki < n <= 2 Mi keys): THREE launches instead of the 8-12 dependent launches of the per-digit
+// passes, which is what these sizes -- every size of the reference's own test, UnitTest/main.cpp:105 -- pay for
+// (~3 us per kernel boundary; profiles/r1_ncurve.txt).
+//   1. mid_prep_kernel      histograms of all four key bytes; the last workgroup to finish picks the MOST SIGNIFICANT
+//                           BYTE THAT VARIES (keys below 2^24, small indices, ... would otherwise all share one
+//                           bucket), and builds the offset tables of pass 2 and the 257 bucket bounds of pass 3
+//   2. onesweep_chain_kernel one MSD pass on that byte (16 look-back chains = 16 slices of the input), data -> tmp
+//   3. segment_sort_kernel  every bucket finished in LDS on the bytes below, tmp -> data
+// Skewed keys can leave a bucket larger than the LDS tile; its workgroup then sorts it through global memory
+// (segment_sort_kernel): correct for any input, slow for adversarial ones ("sort.mid" = 0 turns the path off).
 // ------------------------------------------------------------------------------------------
-template <typename E, int K, int LBITS, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void segment_sort_wave_kernel(E* data, const uint32_t* __restrict__ seg_start,
-                                                                        uint32_t num_segments, uint32_t low_bits,
-                                                                        const uint32_t* __restrict__ gate, uint32_t gate_value,
-                                                                        uint32_t* fault)
+constexpr int kMidChunk = 8192;       // elements per histogram workgroup (two 4 Ki-element tiles of pass 2)
+constexpr int kMidPrepNT = 256;
+
+struct MidDyn {          // written by mid_prep_kernel, read by the kernels after it
+    uint32_t start_bit;  // first bit of the MSD byte
+    uint32_t low_bits;   // bits below it, finished in LDS
+    uint32_t mode;       // 0: passes 2 and 3 run (every bucket fits the LDS tile); 1: they return at once and the
+                         // cooperative LSD kernel sorts instead (skewed keys: a bucket would not fit)
+    uint32_t max_bucket; // largest bucket (diagnostic)
+};
+
+template <typename E>
+__global__ __launch_bounds__(kMidPrepNT) void mid_prep_kernel(const E* __restrict__ src, uint32_t n, uint32_t tile,
+                                                              uint32_t* __restrict__ slice_hist /*[16][4][256], zero on entry*/,
+                                                              PassTable* __restrict__ table, uint32_t* __restrict__ seg_start,
+                                                              MidDyn* __restrict__ dyn, u32x4* __restrict__ tickets,
+                                                              u32x4* __restrict__ status, uint32_t status_vecs,
+                                                              uint32_t* __restrict__ done, uint32_t* __restrict__ fault,
+                                                              uint32_t bucket_cap, uint32_t* __restrict__ host_mode)
 {
-    if (gate && *gate != gate_value) return;
-    constexpr int CAP = 64 * K;
-    constexpr int BINS = 1 << LBITS;
-    constexpr int BPL = BINS / 64;                       // bins per lane in the scan
-    static_assert(BPL >= 1 && BPL <= 8, "bins per lane");
+    __shared__ uint32_t hist[4][256];
+    __shared__ uint32_t s_wsum[kMidPrepNT / 64 + 1];
+    __shared__ uint32_t s_misc[8];
+    const int tid = (int)threadIdx.x;
+    const uint32_t wgs = gridDim.x;
+    const uint32_t wps = (wgs + (uint32_t)kChains - 1u) / (uint32_t)kChains;   // workgroups per slice (= chain of pass 2)
+    {   // tickets and status rows of pass 2, the live fault word
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        if (blockIdx.x == 0) {
+            for (int i = tid; i < kChains * kTicketStride * 4 / 16; i += kMidPrepNT) tickets[i] = z;
+            if (tid == 0) fault[0] = 0u;
+        }
+        for (uint32_t i = blockIdx.x * kMidPrepNT + (uint32_t)tid; i < status_vecs; i += wgs * kMidPrepNT) status[i] = z;
+    }
+    for (int i = tid; i < 4 * 256; i += kMidPrepNT) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    const uint32_t begin = blockIdx.x * (uint32_t)kMidChunk;
+    const uint32_t end = (begin + (uint32_t)kMidChunk < n) ? begin + (uint32_t)kMidChunk : n;
+    auto bump = [&](uint32_t k) {
+        atomicAdd(&hist[0][k & 255u], 1u);
+        atomicAdd(&hist[1][(k >> 8) & 255u], 1u);
+        atomicAdd(&hist[2][(k >> 16) & 255u], 1u);
+        atomicAdd(&hist[3][k >> 24], 1u);
+    };
+    {
+        constexpr int VEC = 16 / (int)sizeof(E);
+        struct alignas(16) Vec { E v[VEC]; };
+        const uint32_t nvec = (end - begin) / VEC;
+        const Vec* vsrc = reinterpret_cast<const Vec*>(src + begin);   // begin is a multiple of the chunk: 16-byte aligned
+        for (uint32_t i = (uint32_t)tid; i < nvec; i += kMidPrepNT) {
+            const Vec v = vsrc[i];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) bump((uint32_t)v.v[k]);
+        }
+        for (uint32_t i = begin + nvec * VEC + (uint32_t)tid; i < end; i += kMidPrepNT) bump((uint32_t)src[i]);
+    }
+    __syncthreads();
+    // add this workgroup's counts to its slice's row (a slice = `wps` consecutive workgroups = one chain of pass 2)
+    uint32_t* row = slice_hist + (size_t)(blockIdx.x / wps) * 1024;
+    for (int i = tid; i < 1024; i += kMidPrepNT) {
+        const uint32_t c = (&hist[0][0])[i];
+        if (c) atomicAdd(row + i, c);
+    }
+    // ---- the last workgroup to get here builds the tables (every other one is done) ------------------------------
+    // The rows are only ever touched by agent-scope atomics (performed at the memory side, never cached in an L1 or a
+    // non-coherent L2), so all the hand-off needs is that this workgroup's adds have been acknowledged before it counts
+    // itself done: no cache write-back or invalidate (an agent-scope fence pair costs ~3.5 us, MI355X_MICROARCH.md).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_misc[0] = atomicAdd(done, 1u);
+    __syncthreads();
+    if (s_misc[0] != wgs - 1u) return;
+    // thread t owns value t of every byte: the sixteen slice rows in ONE round trip, then the rows are cleared for the
+    // next sort on this handle (the area belongs to the device handle and is zero between sorts)
+    uint32_t sl[kChains][4];
+#pragma unroll
+    for (int c = 0; c < kChains; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            sl[c][k] = __hip_atomic_load(slice_hist + (size_t)c * 1024 + k * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int c = 0; c < kChains; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            __hip_atomic_store(slice_hist + (size_t)c * 1024 + k * 256 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // grid-barrier counter of the cooperative LSD kernel
+    }
+    uint32_t tot[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int c = 0; c < kChains; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tot[k] += sl[c][k];
+    int b = 0;   // most significant byte with more than one value present (all keys equal: byte 0)
+#pragma unroll
+    for (int k = 3; k >= 1; --k) {
+        const int present = __syncthreads_count(tot[k] != 0u);
+        if (b == 0 && present > 1) b = k;
+    }
+    const uint32_t total_b = b == 3 ? tot[3] : (b == 2 ? tot[2] : (b == 1 ? tot[1] : tot[0]));
+    const uint32_t gbase = block_excl_scan_u32<kMidPrepNT>(total_b, s_wsum, nullptr);
+    seg_start[tid] = gbase;
+    if (tid == 0) seg_start[256] = n;
+    {   // largest bucket (diagnostic)
+        uint32_t mx = total_b;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)mx, o);
+            mx = other > mx ? other : mx;
+        }
+        if ((tid & 63) == 0) s_misc[1 + (tid >> 6)] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t m4 = s_misc[1];
+            for (int i = 1; i < kMidPrepNT / 64; ++i) m4 = s_misc[1 + i] > m4 ? s_misc[1 + i] : m4;
+            dyn->start_bit = 8u * (uint32_t)b;
+            dyn->low_bits = 8u * (uint32_t)b;
+            dyn->mode = m4 > bucket_cap ? 1u : 0u;
+            dyn->max_bucket = m4;
+            // tell the host (pinned memory, read without synchronising at its next call): 1 + mode of this sort
+            __hip_atomic_store(host_mode, 1u + (m4 > bucket_cap ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    uint32_t run = gbase;
+#pragma unroll
+    for (int c = 0; c < kChains; ++c) {
+        table->cbase[c][tid] = run;
+        run += b == 3 ? sl[c][3] : (b == 2 ? sl[c][2] : (b == 1 ? sl[c][1] : sl[c][0]));
+    }
+    if (tid <= kChains) {
+        const uint64_t e0 = (uint64_t)tid * wps * (uint64_t)kMidChunk;
+        const uint32_t es = e0 < n ? (uint32_t)e0 : n;
+        table->chunk_start[tid] = es;
+        table->tile_start[tid] = (es + tile - 1u) / tile;   // slices are whole tiles except the last one
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The mid-size sort's safety net: ONE launch that does the whole 4 x 8-bit LSD sort with grid-wide barriers between
+// its phases.  It is always enqueued behind passes 2 and 3 and returns at its first instruction unless
+// mid_prep_kernel found a bucket that does not fit the LDS tile (MidDyn::mode = 1: clustered / low-entropy keys).
+// A skewed input therefore costs about 2-3x the per-digit passes instead of one workgroup sorting a huge bucket
+// alone (measured before this existed: 1.5-2.7 ms for 1 Mi clustered keys, profiles/r2_mid_size_distributions.txt),
+// and a friendly one pays one empty launch.  Per pass: every workgroup counts the digits of its run of tiles ->
+// barrier -> workgroup d scans row d of the bucket-major table (the reference's table layout,
+// RadixSort32Kernels.cl:233) -> barrier -> every workgroup scatters its tiles with a per-digit carry -> barrier.
+// All workgroups are resident at once (at most one per CU is needed and each takes ~1/8 of a CU's LDS); every
+// spin is bounded and raises the device fault word when it gives up.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t& target, uint32_t wgs, uint32_t* fault)
+{
+    __shared__ uint32_t ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this workgroup's stores leave the XCD's L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        target += wgs;
+        uint32_t spins = 0u, good = 1u;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > (1u << 24)) { good = 0u; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!good) raise_fault(fault, 0x80000u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop what this CU's L1 holds of other workgroups' data
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ok = good;
+    }
+    __syncthreads();
+    return ok != 0u;
+}
+
+template <typename E, int NT, int K>
+__global__ __launch_bounds__(NT) void coop_lsd_sort_kernel(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table /*[256][wgs]*/,
+                                                           uint32_t* __restrict__ totals /*[256]*/, uint32_t* bar,
+                                                           const uint32_t* __restrict__ dyn, uint32_t* fault)
+{
+    if (dyn[2] == 0u) return;
+    using C = TileCfg<E, 8, NT, K>;
+    constexpr int NW = NT / 64;
+    static_assert(NT >= 256, "one thread per digit");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = (int)threadIdx.x & 63;
-    const int w = (int)threadIdx.x >> 6;
-    unsigned char* mine = smem + (size_t)w * (sizeof(E) * CAP + sizeof(uint32_t) * BINS);
-    E* __restrict__ s_elems = reinterpret_cast<E*>(mine);
-    uint32_t* __restrict__ s_cnt = reinterpret_cast<uint32_t*>(mine + sizeof(E) * CAP);
-
-    const uint32_t seg = blockIdx.x * (uint32_t)WAVES + (uint32_t)w;
-    if (seg >= num_segments) return;
-    const uint32_t begin = seg_start[seg];
-    const uint32_t m = seg_start[seg + 1] - begin;
-    if (m == 0u) return;
-    if (m > (uint32_t)CAP) {   // cannot happen when the mode word says "hybrid"; never sort wrongly in silence
-        if (lane == 0) atomicOr(fault + 1, 0x40000u);   // sticky word
-        return;
-    }
-    E* seg_ptr = data + begin;
-    const int keff = (int)((m + 63u) >> 6);
-    const int rem = (int)m - lane;                       // item j of this lane exists iff j*64 < rem
-    E e[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j)
-        if (j < keff) e[j] = (j * 64 < rem) ? seg_ptr[j * 64 + lane] : E(0);
-
-    const int npass = ((int)low_bits + LBITS - 1) / LBITS;
-    int sb = 0;
-    for (int p = 0; p < npass; ++p) {
-        const int nb = ((int)low_bits - sb + (npass - p - 1)) / (npass - p);
-        const uint32_t mask = (1u << nb) - 1u;
-        auto digit = [&](E x) -> uint32_t { return ((uint32_t)x >> sb) & mask; };
-#pragma unroll
-        for (int q = 0; q < BPL; ++q) s_cnt[q * 64 + lane] = 0u;
-        uint32_t rnk[K];
-        bool uniform;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem + C::OFF_WCNT);   // [NW][256]
+    uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + C::OFF_WSUM);
+    const int tid = (int)threadIdx.x;
+    const int w = tid >> 6;
+    const uint32_t wg = blockIdx.x, wgs = gridDim.x;
+    const uint32_t tiles = (n + (uint32_t)C::TILE - 1u) / (uint32_t)C::TILE;
+    const uint32_t per = (tiles + wgs - 1u) / wgs;
+    const uint32_t t0 = wg * per < tiles ? wg * per : tiles;
+    const uint32_t t1 = t0 + per < tiles ? t0 + per : tiles;
+    const uint32_t e0 = t0 * (uint32_t)C::TILE;
+    const uint32_t e1 = (uint64_t)t1 * C::TILE < n ? t1 * (uint32_t)C::TILE : n;
+    uint32_t target = 0u;   // mid_prep_kernel leaves the barrier counter at zero (done[1])
+    E* src = data;
+    E* dst = tmp;
+    for (int sb = 0; sb < 32; sb += 8) {
+        // ---- count the digits of this workgroup's run of tiles --------------------------------------------------------
+        for (int i = tid; i < NW * 256; i += NT) hist[i] = 0u;
+        __syncthreads();
+        for (uint32_t i = e0 + (uint32_t)tid; i < e1; i += (uint32_t)NT)
+            atomicAdd(&hist[w * 256 + (((uint32_t)src[i] >> sb) & 255u)], 1u);
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t c = 0u;
+            for (int i = 0; i < NW; ++i) c += hist[i * 256 + tid];
+            table[(size_t)tid * wgs + wg] = c;
+        }
+        if (!grid_barrier(bar, target, wgs, fault)) return;
+        // ---- workgroup d scans row d (rows d, d + wgs, ... when there are fewer workgroups than digits) ---------------
+        for (uint32_t d = wg; d < 256u; d += wgs) {
+            uint32_t carry = 0u;
+            for (uint32_t base = 0; base < wgs; base += (uint32_t)NT) {
+                const uint32_t j = base + (uint32_t)tid;
+                const uint32_t v = j < wgs ? table[(size_t)d * wgs + j] : 0u;
+                uint32_t tot;
+                const uint32_t ex = block_excl_scan_u32<NT>(v, s_wsum, &tot);
+                if (j < wgs) table[(size_t)d * wgs + j] = carry + ex;
+                carry += tot;
+            }
+            if (tid == 0) totals[d] = carry;
+        }
+        if (!grid_barrier(bar, target, wgs, fault)) return;
+        // ---- scatter this workgroup's tiles, carrying per-digit offsets from tile to tile ------------------------------
         {
-            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)digit(e[0]));
-            bool same = true;
-#pragma unroll
-            for (int j = 0; j < K; ++j)
-                if (j < keff) same &= (j * 64 >= rem) | (digit(e[j]) == d0);
-            uniform = __all(same);
-            if (!uniform) {
-#pragma unroll
-                for (int j = 0; j < K; ++j)
-                    if (j < keff && j * 64 < rem)
-                        rnk[j] = __hip_atomic_fetch_add(&s_cnt[digit(e[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const uint32_t tot_d = tid < 256 ? totals[tid] : 0u;
+            const uint32_t base_d = block_excl_scan_u32<NT>(tot_d, s_wsum, nullptr);
+            uint32_t carry = tid < 256 ? base_d + table[(size_t)tid * wgs + wg] : 0u;
+            const AosIO<E> io{src, dst};
+            for (uint32_t t = t0; t < t1; ++t) {
+                const uint32_t tb = t * (uint32_t)C::TILE;
+                const uint32_t left = n - tb;
+                sort_scatter_tile<AosIO<E>, 8, NT, K, 1>(io, tb, left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE, n, sb, smem,
+                                                         [&](int, uint32_t c) { const uint32_t g = carry; carry += c; return g; });
             }
         }
-        if (!uniform) {   // (a segment whose digits all agree keeps its order: nothing to move in this pass)
-            // exclusive scan of the bins: lane l owns bins [l*BPL, (l+1)*BPL)
-            uint32_t c[BPL];
-            uint32_t tot = 0u;
-#pragma unroll
-            for (int q = 0; q < BPL; ++q) {
-                c[q] = s_cnt[lane * BPL + q];
-                tot += c[q];
-            }
-            uint32_t run = wave_incl_scan_u32(tot) - tot;
-#pragma unroll
-            for (int q = 0; q < BPL; ++q) {
-                s_cnt[lane * BPL + q] = run;
-                run += c[q];
-            }
-#pragma unroll
-            for (int j = 0; j < K; ++j)
-                if (j < keff && j * 64 < rem) s_elems[s_cnt[digit(e[j])] + rnk[j]] = e[j];
-            if (p + 1 < npass) {
-#pragma unroll
-                for (int j = 0; j < K; ++j)
-                    if (j < keff && j * 64 < rem) e[j] = s_elems[j * 64 + lane];
-            }
-        } else if (p + 1 == npass) {
-#pragma unroll
-            for (int j = 0; j < K; ++j)
-                if (j < keff && j * 64 < rem) s_elems[j * 64 + lane] = e[j];
-        }
-        sb += nb;
+        if (!grid_barrier(bar, target, wgs, fault)) return;
+        E* t = src; src = dst; dst = t;
     }
-#pragma unroll
-    for (int j = 0; j < K; ++j)
-        if (j < keff && j * 64 < rem) seg_ptr[j * 64 + lane] = s_elems[j * 64 + lane];
 }
 
 }  // namespace adlhip

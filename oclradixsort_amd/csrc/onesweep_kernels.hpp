@@ -406,10 +406,14 @@ __device__ __forceinline__ u32x4 lookback_exclusive4(__amdgpu_buffer_rsrc_t rsrc
 template <typename IO, int NBITS, int NT, int K, int RANK>
 __global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTable* __restrict__ table, uint32_t* status,
                                                             uint32_t status_bytes, uint32_t* tickets, uint32_t* fault,
-                                                            uint32_t n, int start_bit)
+                                                            uint32_t n, int start_bit, const uint32_t* __restrict__ dyn_start_bit)
 {
     typedef typename IO::elem_t E;
     using C = TileCfg<E, NBITS, NT, K>;
+    if (dyn_start_bit) {   // the mid-size sort picks its digit position on the device (MidDyn: start_bit, low_bits, mode)
+        if (dyn_start_bit[2] != 0u) return;   // ... and may hand the input to its cooperative LSD kernel instead
+        start_bit = (int)dyn_start_bit[0];
+    }
     constexpr int BINS = C::BINS;
     constexpr int NW = C::NW;
     constexpr int BK_LANES = BINS / 4;   // bookkeeping lanes: 4 digits each

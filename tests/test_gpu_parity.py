@@ -595,7 +595,9 @@ def test_pipelined_sort_stream_over_rccl_one_rank():
         # sort stage: the local sorts (several passes per batch, the 5-key batch in one workgroup)
         assert prof[1].get("count_u32_8b", (0, 0))[0] == 3 and prof[1].get("scatter_u32_8b", (0, 0))[0] == 3, prof[1]
         assert not any(k.startswith(("onesweep", "small_sort")) for k in prof[1]), prof[1]
-        assert prof[2].get("scatter_u32_8b", (0, 0))[0] >= 8 and "small_sort_u32" in prof[2], prof[2]
+        # 1Mi and 300007 keys: the mid-size sort, or (after the skewed batches above) the per-digit passes
+        assert any(k.startswith(("segment_sort", "scatter")) for k in prof[2]) and "small_sort_u32" in prof[2], prof[2]
+        assert not any(k.startswith(("mid_prep", "segment_sort")) for k in prof[1]), prof[1]
         # the serial driver gives the same answer through the same collectives
         r = sorter.sort(dev_in[1].clone(), force_exchange=True)
         assert np.array_equal(r.cpu().numpy().view(np.uint32), oracle.sort_u32(ins[1]))
@@ -863,8 +865,8 @@ def _segment_sort_expected(arr, starts, low_bits):
     return arr[order]
 
 
-@pytest.mark.parametrize("kind,cap", [(0, 1536), (0, 2560), (0, 4096), (0, 8192), (0, 16384), (1, 1280), (1, 4096), (1, 8192)],
-                         ids=["u32-wave1536", "u32-wave2560", "u32-4Ki", "u32-8Ki", "u32-16Ki", "kv-wave1280", "kv-4Ki", "kv-8Ki"])
+@pytest.mark.parametrize("kind,cap", [(0, 4096), (0, 8192), (0, 16384), (1, 4096), (1, 8192)],
+                         ids=["u32-4Ki", "u32-8Ki", "u32-16Ki", "kv-4Ki", "kv-8Ki"])
 def test_segment_sort_in_lds(dev, kind, cap):
     lib = _lib.load()
     rng = np.random.RandomState(cap + kind)

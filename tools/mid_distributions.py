@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Mid-size sort on skewed inputs: us/sort with the mid-size path on / off (what does the through-memory path cost?)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oclradixsort_amd import Buffer, DeviceUtils, Pprims, Stopwatch
+d = DeviceUtils.allocate(); p = Pprims()
+rng = np.random.RandomState(1)
+for n in (1 << 18, 1 << 20):
+    u = rng.randint(0, 2**32, n, dtype=np.uint64)
+    cases = {
+        "uniform": u,
+        "below 2^24 (small indices)": u >> 8,
+        "below 2^12": u >> 20,
+        "two clusters (int32 +-small)": np.where(u & 1, u >> 16, 0xffff0000 | (u >> 16)),
+        "two values": (u & 1) * 0xffffffff,
+        "all equal": np.full(n, 12345, dtype=np.uint64),
+        "sorted": np.sort(u),
+        "top byte only": (u >> 24) << 24,
+        "exponential": (rng.exponential(2.0**24, n)).astype(np.uint64) & 0xffffffff,
+        "90% in one top byte": np.where(rng.rand(n) < 0.9, u >> 8, u),
+    }
+    print("n = %d" % n)
+    for nm, k in cases.items():
+        k = k.astype(np.uint32)
+        res = []
+        for mid in (1, 0):
+            d.setParam("sort.mid", mid)
+            bufs = [Buffer(d, n, np.uint32) for _ in range(8)]
+            best = 1e9
+            for trial in range(3):
+                for b in bufs: b.write(k)
+                DeviceUtils.waitForCompletion(d)
+                sw = Stopwatch(d); sw.start()
+                for b in bufs: p.radixSort(d, b, n)
+                sw.stop()
+                best = min(best, sw.getMs() / len(bufs))
+            ok = np.array_equal(bufs[0].toHost(), np.sort(k))
+            res.append((best * 1e3, ok))
+            for b in bufs: b.release()
+        print("  %-30s mid=1 %8.1f us %s   mid=0 %8.1f us %s" % (nm, res[0][0], "OK" if res[0][1] else "WRONG", res[1][0], "OK" if res[1][1] else "WRONG"), flush=True)
+p.close(); DeviceUtils.deallocate(d)
