@@ -264,13 +264,24 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      0 = onesweep (one sweep per digit, 16 decoupled look-back chains)
  *                      1 = three kernels per pass: count -> table scan -> sort+scatter (the
  *                          reference's pass structure, Pprims.cpp:357-398)
- *   "sort.digit_bits"  8 [default] or 4 (4 = the reference's R32SORT_BITS_PER_PASS, Pprims.h:31)
+ *   "sort.digit_bits"  8 [default], 4 (the reference's R32SORT_BITS_PER_PASS, Pprims.h:31) or 7 (one-sweep passes only: 7,7,7,7,4)
  *   "sort.tile"        tile geometry variant (threads x elements per thread): -1 [default] = best known
  *                      per element size (512x32 for 4-byte, 1024x16 for 8-byte elements); 0 = 256x16,
  *                      1 = 512x16, 2 = 1024x16, 3 = 512x8, 4 = 1024x8, 5 = 256x32, 6 = 512x32
  *   "sort.rank"        1 [default when the device self-test passes] = in-tile ranking by lane-ordered
- *                      returning LDS atomics; 0 = ranking by 64-lane ballot match
+ *                      returning LDS atomics; 0 = ranking by 64-lane ballot match.  Mode 1 depends on a
+ *                      hardware behaviour no ISA document promises (lanes of ONE returning DS atomic
+ *                      instruction that hit the same address are served in ascending lane order); it is
+ *                      checked at device creation and can be re-checked at any time
+ *                      (adlhip_selftest_lds_order).  Mode 0 is the safe fallback: documented wave
+ *                      intrinsics only, ~1.6x the pass time.  Every LSD pass must be stable, so key-only
+ *                      sorts depend on this as much as key-value sorts do.
  *   "sort.lds_ordered" (read-only) result of that self-test
+ *   "sort.mid"         1 [default] / 0: between 16 Ki and 2 Mi keys (1 Mi pairs), full 32-bit sorts take
+ *                      three launches (byte histograms, one MSD pass, buckets finished in LDS) instead of
+ *                      the per-digit passes; skewed keys are detected on the device and handled by a
+ *                      cooperative LSD kernel, and the handle then avoids the path for its next eight
+ *                      eligible sorts (speed only; results never depend on it)
  *   "profile"          0/1: bracket every kernel launch with hipEvents (Device::toggleProfiling,
  *                          Adl/Adl.h:142, AdlKernelUtilsCL.inl:654-677) */
 int adlhip_set_param(adlhip_device* dev, const char* name, int value);
