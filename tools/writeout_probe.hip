@@ -11,6 +11,9 @@
 //   mode 4  hand-over emulation: every tile writes whole 128-byte lines only; the head line of a run is
 //           completed with the predecessor tile's trailing keys (read from a hand-over area, sc1), the
 //           run's own trailing partial line goes to the tile's hand-over slot (sc1) instead of the destination
+//   mode 5  16 bytes per lane: a lane owns four consecutive tile positions; when they belong to one run (15 of 16 lanes
+//           at 64-key runs) it stores them with one dwordx4 (4-byte aligned), otherwise with four dword stores
+//   mode 6  8 bytes per lane: two consecutive tile positions, one dwordx2 when they share a run
 //   hipcc --offload-arch=gfx950 -O3 -o tools/writeout_probe tools/writeout_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -95,6 +98,34 @@ __global__ __launch_bounds__(NT) void writeout_probe(const uint32_t* __restrict_
             const uint32_t g = s_goff[v & 255u] + pos;
             if (g < n) dst[g] = v;
         }
+    } else if (mode == 5) {
+#pragma unroll 4
+        for (int j = 0; j < K / 4; ++j) {
+            const uint32_t pos = (uint32_t)(tid + j * NT) * 4u;
+            const uint4 v = *reinterpret_cast<const uint4*>(s_elems + pos);
+            const uint32_t g0 = s_goff[v.x & 255u] + pos;
+            if ((v.x & 255u) == (v.w & 255u)) {
+                if (g0 + 3u < n) __builtin_memcpy(dst + g0, &v, 16);   // one 16-byte store, 4-byte aligned
+            } else {
+                if (g0 < n) dst[g0] = v.x;
+                const uint32_t g1 = s_goff[v.y & 255u] + pos + 1u; if (g1 < n) dst[g1] = v.y;
+                const uint32_t g2 = s_goff[v.z & 255u] + pos + 2u; if (g2 < n) dst[g2] = v.z;
+                const uint32_t g3 = s_goff[v.w & 255u] + pos + 3u; if (g3 < n) dst[g3] = v.w;
+            }
+        }
+    } else if (mode == 6) {
+#pragma unroll 8
+        for (int j = 0; j < K / 2; ++j) {
+            const uint32_t pos = (uint32_t)(tid + j * NT) * 2u;
+            const uint2 v = *reinterpret_cast<const uint2*>(s_elems + pos);
+            const uint32_t g0 = s_goff[v.x & 255u] + pos;
+            if ((v.x & 255u) == (v.y & 255u)) {
+                if (g0 + 1u < n) __builtin_memcpy(dst + g0, &v, 8);
+            } else {
+                if (g0 < n) dst[g0] = v.x;
+                const uint32_t g1 = s_goff[v.y & 255u] + pos + 1u; if (g1 < n) dst[g1] = v.y;
+            }
+        }
     } else if (mode <= 3) {
         const uint32_t gid = (uint32_t)tid / (uint32_t)W, l = (uint32_t)tid % (uint32_t)W, ng = (uint32_t)NT / (uint32_t)W;
 #pragma unroll 4
@@ -162,8 +193,8 @@ void run(size_t n, size_t lds_kib)
     HK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; HK(hipEventCreate(&e0)); HK(hipEventCreate(&e1));
     printf("tile %d x %d = %d keys, LDS %zu KiB per workgroup -> %d workgroup(s) per CU; n = %zu keys, %u tiles\n", NT, K, TILE, lds_kib, (int)(160 / lds_kib), n, tiles);
-    const char* names[] = {"0 position-major (today)", "1 aligned 128-B lines (half-wave)", "2 aligned 256-B blocks (wave)", "3 aligned 64-B sectors (quarter-wave)", "4 hand-over: whole lines only"};
-    for (int mode = 0; mode <= 4; ++mode) {
+    const char* names[] = {"0 position-major (today)", "1 aligned 128-B lines (half-wave)", "2 aligned 256-B blocks (wave)", "3 aligned 64-B sectors (quarter-wave)", "4 hand-over: whole lines only", "5 16 bytes per lane where a run allows", "6 8 bytes per lane where a run allows"};
+    for (int mode : {0, 5, 6, 0, 5, 6}) {
         for (int k = 0; k < 3; ++k) { kern<<<tiles, NT, lds>>>(a, b, dg, dc, ho, tpc, (uint32_t)n, mode); kern<<<tiles, NT, lds>>>(b, a, dg, dc, ho, tpc, (uint32_t)n, mode); }
         HK(hipEventRecord(e0));
         const int reps = 10;
@@ -181,7 +212,5 @@ int main(int argc, char** argv)
 {
     const size_t n = argc > 1 ? strtoull(argv[1], 0, 0) : (size_t)1 << 26;
     run<512, 32>(n, 76);     // today's tile, two workgroups per CU
-    run<1024, 32>(n, 150);   // 32 Ki-key tile, one workgroup per CU
-    run<512, 16>(n, 40);     // 8 Ki-key tile, four workgroups per CU
     return 0;
 }
