@@ -210,8 +210,12 @@ std::vector<PassPlan> plan_passes(int sort_bits, int digit_bits)
     std::vector<PassPlan> p;
     int sb = 0;
     while (sb < sort_bits) {
-        int nb = (digit_bits == 8 && sort_bits - sb >= 8) ? 8 : 4;
-        if (digit_bits == 7 && sort_bits % 7 % 4 == 0 && sort_bits - sb >= 7) nb = 7;   // 7,7,7,7(,4)
+        // 7-bit digits only where the key width allows 7,...,7(,4); every other width falls back to 8-bit digits
+        // (and up to 32 sorted bits: a 7-bit digit starting at bit 28 would straddle the two dwords of a 64-bit key,
+        // which digit_of() rules out)
+        const bool seven = digit_bits == 7 && sort_bits % 7 % 4 == 0 && sort_bits <= 32;
+        int nb = ((digit_bits == 8 || (digit_bits == 7 && !seven)) && sort_bits - sb >= 8) ? 8 : 4;
+        if (seven && sort_bits - sb >= 7) nb = 7;
         p.push_back({sb, nb});
         sb += nb;
     }
@@ -241,6 +245,7 @@ Geometry geometry(const adlhip_device* d, size_t n, uint32_t tile)
 //   4-byte elements up to 24 MiB: 512 x 16
 int effective_variant(const adlhip_device* d, size_t elem_bytes, size_t n)
 {
+    if (d->digit_bits == 7) return elem_bytes == 4 ? 6 : 2;   // 7-bit digits are instantiated for the default large tiles only
     if (d->tile_variant >= 0) return d->tile_variant;
     if (n * elem_bytes <= (size_t(8) << 20)) return 0;
     // 4-byte keys between 8 and 24 MiB (three-kernel passes): 512 x 16 (8 Ki keys) -- 4Mi keys 75 vs 79 us with 512 x 32
@@ -648,7 +653,7 @@ int launch_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* s
     const uint32_t grid = (uint32_t)std::min<size_t>(num_segments, per_cu * (size_t)d->prop.multiProcessorCount);
     return launch(d, sizeof(E) == 4 ? "segment_sort_u32" : "segment_sort_e64", [&] {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, d->stream, in, out, seg_start, (uint32_t)num_segments, (uint32_t)low_bits,
-                           dyn, (const uint32_t*)nullptr, 0u, d->d_fault);
+                           dyn, d->d_fault);
     });
 }
 

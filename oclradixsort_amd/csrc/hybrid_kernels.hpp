@@ -20,14 +20,6 @@
 
 namespace adlhip {
 
-constexpr int kMsdBits = 7;                     // digit width of passes A and B
-constexpr int kMsdBuckets = 1 << kMsdBits;      // 128
-constexpr int kSegments = 1 << (2 * kMsdBits);  // 16384
-constexpr int kLocalPassesMax = 3;               // local passes of the finishing kernel (LBITS bits each at most)
-
-constexpr uint32_t kModeHybrid = 0u;            // mode word values (work buffer)
-constexpr uint32_t kModeClassic = 1u;
-
 // ------------------------------------------------------------------------------------------
 // C: finish segments in LDS.  A workgroup takes segments blockIdx.x, blockIdx.x + gridDim.x, ...  The segment
 // [seg_start[s], seg_start[s+1]) of `in` is loaded once, sorted on its low `low_bits` bits with up to three stable
@@ -50,11 +42,8 @@ constexpr uint32_t kModeClassic = 1u;
 template <typename E, int NT, int K, int LBITS>
 __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, const uint32_t* __restrict__ seg_start,
                                                           uint32_t num_segments, uint32_t low_bits_arg,
-                                                          const uint32_t* __restrict__ dyn,
-                                                          const uint32_t* __restrict__ gate, uint32_t gate_value,
-                                                          uint32_t* fault)
+                                                          const uint32_t* __restrict__ dyn, uint32_t* fault)
 {
-    if (gate && *gate != gate_value) return;
     if (dyn && dyn[2] != 0u) return;                   // mid-size sort: the cooperative LSD kernel takes this input
     constexpr int NW = NT / 64;
     constexpr int CAP = NT * K;

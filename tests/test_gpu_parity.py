@@ -21,10 +21,10 @@ pytestmark = pytest.mark.gpu
 
 # (sort.algo, sort.digit_bits, sort.tile, sort.rank)
 ALGOS = [(-1, 8, -1, 1), (-1, 4, -1, 0), (0, 8, -1, 1), (0, 4, -1, 1), (1, 8, -1, 1), (1, 4, -1, 1), (0, 8, -1, 0), (1, 8, 0, 0), (0, 8, 0, 1), (1, 8, 1, 1),
-         (0, 8, 3, 1), (1, 8, 4, 0), (0, 8, 5, 1), (0, 8, 2, 1), (0, 4, 0, 0)]
+         (0, 8, 3, 1), (1, 8, 4, 0), (0, 8, 5, 1), (0, 8, 2, 1), (0, 4, 0, 0), (0, 7, -1, 1)]
 ALGO_IDS = ["auto8", "auto4-ballot", "onesweep8", "onesweep4", "threekernel8", "threekernel4", "onesweep8-ballot", "threekernel8-256x16-ballot",
             "onesweep8-256x16", "threekernel8-512x16", "onesweep8-512x8", "threekernel8-1024x8-ballot",
-            "onesweep8-256x32", "onesweep8-1024x16", "onesweep4-256x16-ballot"]
+            "onesweep8-256x32", "onesweep8-1024x16", "onesweep4-256x16-ballot", "onesweep7"]
 
 
 @pytest.fixture(scope="module")

@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """Soak test of the inter-workgroup look-back protocol: many back-to-back one-sweep sorts of random sizes,
 element kinds and key distributions, every result checked (sortedness + multiset checksum on the device
-result copied back, full oracle comparison for the smaller ones), fault word checked at every sync.
+result copied back, full oracle comparison for the smaller ones), fault word checked at every sync.  Every eighth sort
+is followed -- while later sorts are already queued -- by the LDS-order self-test on a SECOND handle (the hardware
+behaviour "sort.rank" = 1 rests on, adlhip_selftest_lds_order), and one size class reaches past 64 Mi keys (the
+pointer-store write-out).
    python tools/stress.py [--seconds 60]"""
 import argparse, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle
-from oclradixsort_amd import Buffer, DeviceUtils, Pprims
+import ctypes
+from oclradixsort_amd import Buffer, DeviceUtils, Pprims, _lib
+from oclradixsort_amd._lib import check
 ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=60.0); args = ap.parse_args()
 d = DeviceUtils.allocate(); p = Pprims()
+d2 = DeviceUtils.allocate(); selftests = 0
 rng = np.random.RandomState(2026)
 t_end = time.time() + args.seconds
 it = 0; elems = 0
@@ -20,6 +26,7 @@ while time.time() < t_end:
     it += 1
     kind = rng.choice(["u32", "kv", "u64", "soa"])
     n = int(2 ** rng.uniform(10, 25.5)) + int(rng.randint(0, 1000))
+    if kind == "u32" and it % 23 == 0: n = (1 << 26) + int(rng.randint(1, 1 << 22))     # past 256 MiB: pointer stores
     algo = int(rng.choice([0, 0, 0, 1, -1])); bits = int(rng.choice([8, 8, 8, 4])); tile = int(rng.choice([-1, -1, 0, 1, 2, 5]))
     d.setParam("sort.algo", algo); d.setParam("sort.digit_bits", bits); d.setParam("sort.tile", tile)
     dist = rng.choice(["uniform", "lowbits", "fewvals", "sortedish"])
@@ -32,6 +39,11 @@ while time.time() < t_end:
         b = Buffer(d, n, np.uint32); b.write(k)
         reps = int(rng.randint(1, 4))
         for _ in range(reps): p.radixSort(d, b, n)          # re-sorting sorted data stresses the low-entropy paths
+        if it % 8 == 0:   # the ranking's hardware assumption, checked on another stream while these sorts run
+            mism = ctypes.c_uint32(1)
+            check(_lib.load().adlhip_selftest_lds_order(d2._h, 256, ctypes.byref(mism)), "selftest")
+            assert mism.value == 0, ("lds order self-test", it)
+            selftests += 1
         out = b.toHost(); b.release()
         assert np.all(out[1:] >= out[:-1]) and checks(out) == checks(k), (it, kind, n, algo, bits, tile, dist)
         if n < (1 << 22): assert np.array_equal(out, oracle.sort_u32(k)), (it, kind, n)
@@ -53,5 +65,6 @@ while time.time() < t_end:
         b = Buffer(d, n, np.uint64); b.write(k64); p.radixSort64(d, b, n); out = b.toHost(); b.release()
         assert np.all(out[1:] >= out[:-1]) and checks(out) == checks(k64), (it, kind, n, algo, bits, tile, dist)
     elems += n
-print("stress ok: %d sorts, %.1f M elements, %.0f s, no mismatch, no look-back fault" % (it, elems / 1e6, args.seconds))
-p.close(); DeviceUtils.deallocate(d)
+print("stress ok: %d sorts, %.1f M elements, %.0f s, no mismatch, no look-back fault, %d LDS-order self-tests beside running sorts: 0 mismatches"
+      % (it, elems / 1e6, args.seconds, selftests))
+p.close(); DeviceUtils.deallocate(d); DeviceUtils.deallocate(d2)
