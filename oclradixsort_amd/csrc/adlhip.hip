@@ -585,7 +585,7 @@ int onesweep_sort(adlhip_device* d, Buf data, Buf tmp, void* work, size_t n, con
     Buf dst = tmp;
     for (int i = 0; i < P; ++i) {
         uint32_t* st = status + (size_t)i * rows * 256;
-        uint32_t* tk = ctrl + i * 16 * adlhip::kTicketStride;
+        uint32_t* tk = ctrl + i * adlhip::kChains * adlhip::kTicketStride;
         rc = (plan[i].nbits == 8)   ? dispatch_onesweep<Buf, 8>(d, src, dst, tables + i, st, tk, n, plan[i].start_bit)
              : (plan[i].nbits == 7) ? dispatch_onesweep<Buf, 7>(d, src, dst, tables + i, st, tk, n, plan[i].start_bit)
                                     : dispatch_onesweep<Buf, 4>(d, src, dst, tables + i, st, tk, n, plan[i].start_bit);

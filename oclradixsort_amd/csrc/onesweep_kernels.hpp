@@ -48,7 +48,11 @@
 namespace adlhip {
 
 constexpr int kMaxPassesFwd = 16;
-constexpr int kChains = 16;          // independent look-back chains per pass (top nibble of the previous digit)
+#ifndef ADLHIP_CHAIN_BITS
+#define ADLHIP_CHAIN_BITS 4
+#endif
+constexpr int kChainBits = ADLHIP_CHAIN_BITS;
+constexpr int kChains = 1 << kChainBits;   // independent look-back chains per pass (top bits of the previous digit)
 constexpr int kTicketStride = 32;    // u32 words between two chains' ticket counters: one 128-byte line each (sixteen counters
                                      // in ONE line queue every ticket of a pass on the same atomic unit)
 constexpr int kTicketVecs = kMaxPassesFwd * kChains * kTicketStride * 4 / 16;   // 16-byte vectors of the ticket area
@@ -138,11 +142,11 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
             // pass 0 (starts at bit 0; the chain is workgroup-uniform): bin = chain * 2^nb + digit.  With the
             // uniform chain in the LOW bits every lane would hit one of 4 LDS banks.
             if (p == 0) return (chain0 << nb) | ((uint32_t)x & ((1u << nb) - 1u));
-            // p >= 1: bin = digit * 16 + chain = the nb + 4 contiguous key bits from sb - 4 (one v_bfe_u32)
+            // p >= 1: bin = digit * kChains + chain = the nb + kChainBits contiguous key bits from sb - kChainBits (one v_bfe_u32)
             uint32_t v;
-            if constexpr (sizeof(E) == 8) v = (uint32_t)((uint64_t)x >> (sb - 4));
-            else v = (uint32_t)x >> (sb - 4);
-            return v & ((1u << (nb + 4)) - 1u);
+            if constexpr (sizeof(E) == 8) v = (uint32_t)((uint64_t)x >> (sb - kChainBits));
+            else v = (uint32_t)x >> (sb - kChainBits);
+            return v & ((1u << (nb + kChainBits)) - 1u);
         };
         auto bump = [&](E x) {
             uint32_t off = 0u;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
             auto mask_of = [&](int p) -> K {
                 const int sb = desc.start_bit[p];
                 const int nb = desc.nbits[p];
-                return (p == 0) ? (K)((1u << nb) - 1u) : ((K)((1u << (nb + 4)) - 1u) << (sb - 4));
+                return (p == 0) ? (K)((1u << nb) - 1u) : ((K)((1u << (nb + kChainBits)) - 1u) << (sb - kChainBits));
             };
             auto plain = [&](int p, uint32_t off) {
 #pragma unroll
