@@ -277,11 +277,13 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      intrinsics only, ~1.6x the pass time.  Every LSD pass must be stable, so key-only
  *                      sorts depend on this as much as key-value sorts do.
  *   "sort.lds_ordered" (read-only) result of that self-test
- *   "sort.mid"         1 [default] / 0: between 16 Ki and 2 Mi keys (1 Mi pairs), full 32-bit sorts take
- *                      three launches (byte histograms, one MSD pass, buckets finished in LDS) instead of
- *                      the per-digit passes; skewed keys are detected on the device and handled by a
- *                      cooperative LSD kernel, and the handle then avoids the path for its next eight
- *                      eligible sorts (speed only; results never depend on it)
+ *   "sort.mid"         1 [default] / 0: between 16 Ki and 2 Mi keys (1 Mi pairs), full 32-bit sorts take two
+ *                      launches (u32 keys: MSD pass with bucket cursors, buckets finished in LDS) or three
+ *                      (pairs; keys with a constant top byte: byte histograms, stable MSD pass, LDS finish)
+ *                      instead of the per-digit passes.  Keys that do not fit the buckets are detected on the
+ *                      device and sorted by a cooperative LSD sort inside the same launches (correct, slower);
+ *                      the handle then steers later sorts by asynchronous hints (speed only; results never
+ *                      depend on them).  2 / 3 force the two- / three-launch form (tests)
  *   "profile"          0/1: bracket every kernel launch with hipEvents (Device::toggleProfiling,
  *                          Adl/Adl.h:142, AdlKernelUtilsCL.inl:654-677) */
 int adlhip_set_param(adlhip_device* dev, const char* name, int value);

@@ -83,6 +83,8 @@ struct adlhip_device {
     int lds_ordered = 0;      // result of the device self-test at creation
     int mid_path = 1;         // 16 Ki < n <= 2 Mi: MSD pass + LDS finish (three launches) instead of per-digit passes
     int mid_skip = 0;         // eligible sorts still to be sent down the per-digit passes after a skewed input (see mid_eligible)
+    int mid2_skip = 0;        // keys-only sorts still to take the three-launch form after a slab overflow (see mid_sort_keys)
+    int mid_backoff = 32, mid2_backoff = 64;   // how many sorts the next fallback / overflow skips (x8 each time, reset by a success)
     // profiling
     std::vector<PendingProf> pending;
     std::vector<hipEvent_t> event_pool;
@@ -98,7 +100,8 @@ struct adlhip_device {
     uint32_t* d_fault = nullptr;
     uint32_t* h_fault = nullptr;   // pinned: [0..1] filled by adlhip_sync, [4] by the last adlhip_fault_check snapshot
     hipEvent_t fault_snap = nullptr;   // recorded behind the last snapshot copy; null = none pending
-    uint32_t* d_mid_hist = nullptr;    // [16][4][256] slice histograms of the mid-size sort: zero between sorts
+    uint32_t* d_mid_hist = nullptr;    // [16][4][256] slice histograms of the mid-size sort + 512 words of bucket cursors / flags
+                                       // of its keys-only form (hybrid_kernels.hpp SegSlab): zero between sorts
 };
 
 namespace {
@@ -642,7 +645,8 @@ int small_sort(adlhip_device* d, E* data, size_t n, const std::vector<PassPlan>&
 // ---- segments finished in LDS (adlhip_segment_sort; pass 3 of the mid-size sort) -----------------------------------
 template <typename E, int NT, int K, int LBITS>
 int launch_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* seg_start, size_t num_segments, int low_bits,
-                        const uint32_t* dyn)
+                        const uint32_t* dyn, const adlhip::MidCoop& coop = adlhip::MidCoop{nullptr, nullptr, nullptr, 0u},
+                        const adlhip::SegSlab& slab = adlhip::SegSlab{nullptr, 0u, nullptr, nullptr})
 {
     auto kern = adlhip::segment_sort_kernel<E, NT, K, LBITS>;
     const size_t own = sizeof(E) * NT * K + (size_t)(NT / 64) * (1u << LBITS) * 6 + 64;
@@ -653,7 +657,7 @@ int launch_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* s
     const uint32_t grid = (uint32_t)std::min<size_t>(num_segments, per_cu * (size_t)d->prop.multiProcessorCount);
     return launch(d, sizeof(E) == 4 ? "segment_sort_u32" : "segment_sort_e64", [&] {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, d->stream, in, out, seg_start, (uint32_t)num_segments, (uint32_t)low_bits,
-                           dyn, d->d_fault);
+                           dyn, d->d_fault, coop, slab);
     });
 }
 
@@ -687,8 +691,8 @@ constexpr size_t kMidMaxE64 = size_t(1) << 20;
 constexpr uint32_t kMidTile = 4096;   // pass 2 runs on 256 x 16 tiles
 
 struct MidLayout {
-    size_t off_tickets, off_table, off_seg, off_dyn, off_status, off_coop, total;
-    uint32_t wgs, rows, coop_wgs;
+    size_t off_tickets, off_table, off_seg, off_dyn, off_status, off_coop, off_slab, total;
+    uint32_t wgs, rows, coop_wgs, stride;
 };
 
 MidLayout mid_layout(size_t n)
@@ -702,31 +706,67 @@ MidLayout mid_layout(size_t n)
     L.off_dyn = align_up(L.off_seg + 257 * 4, 16);
     L.off_status = align_up(L.off_dyn + sizeof(adlhip::MidDyn), 256);
     // cooperative LSD kernel (safety net for skewed keys): bucket-major table [256][wgs] + 256 totals
-    L.coop_wgs = std::min<uint32_t>(256u, (uint32_t)((n + kMidTile - 1) / kMidTile));
+    L.coop_wgs = 256;   // = the grid of pass 3 (one workgroup per bucket)
     L.off_coop = align_up(L.off_status + (size_t)L.rows * 256 * 4, 256);
-    L.total = L.off_coop + (size_t)256 * L.coop_wgs * 4 + 256 * 4;
+    // keys-only form: 256 bucket slabs of `stride` elements (= the LDS tile of pass 2: at least twice the mean bucket)
+    L.stride = n <= (size_t(512) << 10) ? 4096u : (n <= (size_t(1) << 20) ? 8192u : 16384u);
+    L.off_slab = align_up(L.off_coop + (size_t)256 * L.coop_wgs * 4 + 256 * 4, 256);
+    L.total = L.off_slab + (size_t)256 * L.stride * 4;
     return L;
 }
 
-bool mid_eligible(adlhip_device* d, size_t elem_bytes, size_t n, int sort_bits, int max_bits)
+bool mid_eligible(const adlhip_device* d, size_t elem_bytes, size_t n, int sort_bits, int max_bits)
 {
-    if (!(d->sort_algo < 0 && d->mid_path && max_bits == 32 && sort_bits == 32 && d->rank_mode == 1 && d->digit_bits == 8 &&
-          d->tile_variant < 0 && n > kSmallMax && n <= (elem_bytes == 4 ? kMidMaxU32 : kMidMaxE64)))
-        return false;
-    // Skewed keys make the mid-size sort fall back to its cooperative LSD kernel, 3-5x the cost of the per-digit passes
-    // (profiles/r2_mid_size_distributions.txt).  mid_prep_kernel reports each sort's mode into pinned memory; the host looks
-    // at the most recent report WITHOUT synchronising (it may be a sort or two old) and, after a fallback, sends the next
-    // eight eligible sorts of this handle down the per-digit passes before it tries again.  Only speed depends on this.
+    return d->sort_algo < 0 && d->mid_path && max_bits == 32 && sort_bits == 32 && d->rank_mode == 1 && d->digit_bits == 8 &&
+           d->tile_variant < 0 && n > kSmallMax && n <= (elem_bytes == 4 ? kMidMaxU32 : kMidMaxE64);
+}
+
+// Which form an eligible sort takes: 2 = two launches (u32 keys only), 3 = three launches, 0 = the per-digit passes.
+// Both mid-size forms fall back to a cooperative LSD sort when the keys do not fit their buckets -- correct, but 3-5x the cost
+// of the per-digit passes (profiles/r2_mid_size_distributions_every_sort_through_mid_path.txt) -- and report what happened into
+// pinned memory (hybrid_kernels.hpp: mid_prep_kernel, SegSlab::host_mode).  The host reads the latest reports WITHOUT
+// synchronising (they may be a sort or two old) and steers by them:
+//   two-launch form overflowed, top byte constant  -> this handle's next 64 eligible sorts take the three-launch form
+//                                                     (it picks the byte that varies); 512, 4096 after repeats
+//   two-launch form overflowed, several buckets    -> ... and the next 32 (256, 2048, 4096) take the per-digit passes
+//   three-launch form fell back                    -> the next 32 (256, ...) take the per-digit passes
+// A success resets the respective count.  Only speed depends on any of this; "sort.mid" = 2 / 3 force a form, 0 = off.
+int choose_mid_form(adlhip_device* d, bool keys_only)
+{
+    if (d->mid_path == 2) return keys_only ? 2 : 3;
+    if (d->mid_path == 3) return 3;
+    if (keys_only) {
+        if (d->mid2_skip > 0) {
+            --d->mid2_skip;
+        } else {
+            const uint32_t report = d->h_fault[10];
+            d->h_fault[10] = 0u;
+            if (report >= 2u) {
+                d->mid2_skip = d->mid2_backoff;
+                d->mid2_backoff = std::min(d->mid2_backoff * 8, 4096);
+                if (report == 2u) {
+                    d->mid_skip = std::max(d->mid_skip, d->mid_backoff);
+                    d->mid_backoff = std::min(d->mid_backoff * 8, 4096);
+                }
+            } else {
+                if (report == 1u) d->mid2_backoff = 64;
+                return 2;
+            }
+        }
+    }
     if (d->mid_skip > 0) {
         --d->mid_skip;
-        return false;
+        return 0;
     }
-    if (d->h_fault[9] == 2u) {
-        d->h_fault[9] = 0u;
-        d->mid_skip = 8;
-        return false;
+    const uint32_t report = d->h_fault[9];
+    d->h_fault[9] = 0u;
+    if (report == 2u) {
+        d->mid_skip = d->mid_backoff;
+        d->mid_backoff = std::min(d->mid_backoff * 8, 4096);
+        return 0;
     }
-    return true;
+    if (report == 1u) d->mid_backoff = 32;
+    return 3;
 }
 
 template <typename E>
@@ -752,17 +792,44 @@ int mid_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     if (rc) return rc;
     rc = launch_onesweep<AosBuf<E>, 8, 256, 16, 1>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, table, status, tickets, n, 24, &dyn->start_bit);
     if (rc) return rc;
-    rc = segment_sort<E>(d, tmp, data, seg_start, 256, cap, 24, &dyn->start_bit);
-    if (rc) return rc;
-    // the safety net: returns at once unless mid_prep_kernel found a bucket beyond `cap`
-    using CC = adlhip::TileCfg<E, 8, 256, 16>;
-    auto coop = adlhip::coop_lsd_sort_kernel<E, 256, 16>;
-    if (ensure_lds(coop, CC::LDS_BYTES)) return ADLHIP_FAILURE;
+    // pass 3: 8-bit local digits (the bytes below the MSD byte); its workgroups double as the cooperative LSD sort that takes
+    // over when mid_prep_kernel found a bucket beyond `cap` (the grid is 256 workgroups either way)
     uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
-    return launch(d, sizeof(E) == 4 ? "mid_coop_lsd_u32" : "mid_coop_lsd_e64", [&] {
-        hipLaunchKernelGGL(coop, dim3(L.coop_wgs), dim3(256), CC::LDS_BYTES, d->stream, data, tmp, (uint32_t)n, ctable,
-                           ctable + (size_t)256 * L.coop_wgs, d->d_fault + 13, (const uint32_t*)&dyn->start_bit, d->d_fault);
+    const adlhip::MidCoop coop{ctable, ctable + (size_t)256 * 256, d->d_fault + 13, (uint32_t)n};
+    const uint32_t* dd = &dyn->start_bit;
+    if (sizeof(E) == 4) {
+        if (cap <= 4096) return launch_segment_sort<E, 256, 16, 8>(d, tmp, data, seg_start, 256, 24, dd, coop);
+        if (cap <= 8192) return launch_segment_sort<E, 512, 16, 8>(d, tmp, data, seg_start, 256, 24, dd, coop);
+        return launch_segment_sort<E, 512, 32, 8>(d, tmp, data, seg_start, 256, 24, dd, coop);
+    }
+    if (cap <= 4096) return launch_segment_sort<E, 256, 16, 8>(d, tmp, data, seg_start, 256, 24, dd, coop);
+    return launch_segment_sort<E, 512, 16, 8>(d, tmp, data, seg_start, 256, 24, dd, coop);
+}
+
+// Keys-only form (u32 keys: the pass on the top byte need not be stable, hybrid_kernels.hpp msd_bucket_scatter_kernel):
+// TWO launches.  Its buckets are fixed to the top byte, so keys that share it (anything below 2^24) or are otherwise skewed
+// overflow a slab; pass 2 then runs the cooperative LSD sort (correct, slow) and reports it (choose_mid_form).
+int mid_sort_keys(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, size_t n)
+{
+    typedef uint32_t E;
+    const MidLayout L = mid_layout(n);
+    char* wb = reinterpret_cast<char*>(work);
+    E* slab = reinterpret_cast<E*>(wb + L.off_slab);
+    uint32_t* state = d->d_mid_hist + 16 * 1024;
+    using CA = adlhip::TileCfg<E, 8, 256, 16>;
+    auto ka = adlhip::msd_bucket_scatter_kernel<E, 256, 16>;
+    if (ensure_lds(ka, CA::LDS_BYTES)) return ADLHIP_FAILURE;
+    const uint32_t tiles = (uint32_t)((n + kMidTile - 1) / kMidTile);
+    int rc = launch(d, "mid_bucket_scatter_u32", [&] {
+        hipLaunchKernelGGL(ka, dim3(tiles), dim3(256), CA::LDS_BYTES, d->stream, (const E*)data, slab, state, (uint32_t)n, L.stride);
     });
+    if (rc) return rc;
+    uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
+    const adlhip::MidCoop coop{ctable, ctable + (size_t)256 * 256, state + 258, (uint32_t)n};
+    const adlhip::SegSlab sl{state, L.stride, d->h_fault + 10, tmp};
+    if (L.stride <= 4096) return launch_segment_sort<E, 256, 16, 8>(d, slab, data, nullptr, 256, 24, nullptr, coop, sl);
+    if (L.stride <= 8192) return launch_segment_sort<E, 512, 16, 8>(d, slab, data, nullptr, 256, 24, nullptr, coop, sl);
+    return launch_segment_sort<E, 512, 32, 8>(d, slab, data, nullptr, 256, 24, nullptr, coop, sl);
 }
 
 size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)
@@ -829,7 +896,13 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
     if (n == 0) return ADLHIP_SUCCESS;
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
     if (d->sort_algo < 0 && n <= kSmallMax) return small_sort<E>(d, data, n, plan);   // one workgroup, one launch
-    if (mid_eligible(d, sizeof(E), n, sort_bits, max_bits)) return mid_sort<E>(d, data, tmp, work, n);   // three launches
+    if (mid_eligible(d, sizeof(E), n, sort_bits, max_bits)) {
+        const int form = choose_mid_form(d, sizeof(E) == 4);
+        if constexpr (sizeof(E) == 4) {
+            if (form == 2) return mid_sort_keys(d, data, tmp, work, n);   // two launches
+        }
+        if (form == 3) return mid_sort<E>(d, data, tmp, work, n);         // three launches
+    }
     return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, n, plan);
 }
 
@@ -984,7 +1057,8 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         return fail("cannot allocate the fault word");
     }
     memset(d->h_fault, 0, 64);
-    if (hipMalloc(&d->d_mid_hist, 16 * 1024 * 4) != hipSuccess || hipMemsetAsync(d->d_mid_hist, 0, 16 * 1024 * 4, d->stream) != hipSuccess) {
+    if (hipMalloc(&d->d_mid_hist, (16 * 1024 + 512) * 4) != hipSuccess ||
+        hipMemsetAsync(d->d_mid_hist, 0, (16 * 1024 + 512) * 4, d->stream) != hipSuccess) {
         if (d->d_mid_hist) hipFree(d->d_mid_hist);
         hipFree(d->d_fault);
         hipHostFree(d->h_fault);
@@ -1435,7 +1509,7 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
         d->tile_variant = value;
 
     } else if (!strcmp(name, "sort.mid")) {
-        if (value != 0 && value != 1) return fail("sort.mid must be 0 or 1");
+        if (value < 0 || value > 3) return fail("sort.mid must be 0 (off), 1 (on), 2 (keys: always the two-launch form) or 3 (always the three-launch form)");
         d->mid_path = value;
     } else if (!strcmp(name, "sort.rank")) {
         if (value != 0 && value != 1) return fail("sort.rank must be 0 or 1");

@@ -21,6 +21,115 @@
 namespace adlhip {
 
 // ------------------------------------------------------------------------------------------
+// The mid-size sort's safety net: the whole 4 x 8-bit LSD sort with grid-wide barriers between its phases, run by the
+// workgroups of pass 3 (segment_sort_kernel) INSTEAD of their segments when mid_prep_kernel found a bucket that does not
+// fit the LDS tile (MidDyn::mode = 1: clustered / low-entropy keys).  (As a launch of its own it cost 4.6 us per sort
+// even when it had nothing to do: 256 workgroups that load one word and leave.)
+// A skewed input therefore costs about 2-3x the per-digit passes instead of one workgroup sorting a huge bucket
+// alone (measured before this existed: 1.5-2.7 ms for 1 Mi clustered keys, profiles/r2_mid_size_distributions.txt),
+// and a friendly one pays nothing.  Per pass: every workgroup counts the digits of its run of tiles ->
+// barrier -> workgroup d scans row d of the bucket-major table (the reference's table layout,
+// RadixSort32Kernels.cl:233) -> barrier -> every workgroup scatters its tiles with a per-digit carry -> barrier.
+// All workgroups are resident at once (at most one per CU is needed and each takes ~1/8 of a CU's LDS); every
+// spin is bounded and raises the device fault word when it gives up.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t& target, uint32_t wgs, uint32_t* fault)
+{
+    __shared__ uint32_t ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this workgroup's stores leave the XCD's L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        target += wgs;
+        uint32_t spins = 0u, good = 1u;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > (1u << 24)) { good = 0u; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!good) raise_fault(fault, 0x80000u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop what this CU's L1 holds of other workgroups' data
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ok = good;
+    }
+    __syncthreads();
+    return ok != 0u;
+}
+
+struct MidCoop {          // what the safety net needs beside the two arrays (table == nullptr: there is none)
+    uint32_t* table;      // [256][gridDim.x] bucket-major digit table
+    uint32_t* totals;     // [256]
+    uint32_t* bar;        // grid-barrier counter, zero on entry (mid_prep_kernel)
+    uint32_t n;
+};
+
+template <typename E, int NT, int K>
+__device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table, uint32_t* __restrict__ totals,
+                                              uint32_t* bar, uint32_t* fault, unsigned char* smem)
+{
+    using C = TileCfg<E, 8, NT, K>;
+    constexpr int NW = NT / 64;
+    static_assert(NT >= 256, "one thread per digit");
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem + C::OFF_WCNT);   // [NW][256]
+    uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + C::OFF_WSUM);
+    const int tid = (int)threadIdx.x;
+    const int w = tid >> 6;
+    const uint32_t wg = blockIdx.x, wgs = gridDim.x;
+    const uint32_t tiles = (n + (uint32_t)C::TILE - 1u) / (uint32_t)C::TILE;
+    const uint32_t per = (tiles + wgs - 1u) / wgs;
+    const uint32_t t0 = wg * per < tiles ? wg * per : tiles;
+    const uint32_t t1 = t0 + per < tiles ? t0 + per : tiles;
+    const uint32_t e0 = t0 * (uint32_t)C::TILE;
+    const uint32_t e1 = (uint64_t)t1 * C::TILE < n ? t1 * (uint32_t)C::TILE : n;
+    uint32_t target = 0u;   // mid_prep_kernel leaves the barrier counter at zero (done[1])
+    E* src = data;
+    E* dst = tmp;
+    for (int sb = 0; sb < 32; sb += 8) {
+        // ---- count the digits of this workgroup's run of tiles --------------------------------------------------------
+        for (int i = tid; i < NW * 256; i += NT) hist[i] = 0u;
+        __syncthreads();
+        for (uint32_t i = e0 + (uint32_t)tid; i < e1; i += (uint32_t)NT)
+            atomicAdd(&hist[w * 256 + (((uint32_t)src[i] >> sb) & 255u)], 1u);
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t c = 0u;
+            for (int i = 0; i < NW; ++i) c += hist[i * 256 + tid];
+            table[(size_t)tid * wgs + wg] = c;
+        }
+        if (!grid_barrier(bar, target, wgs, fault)) return;
+        // ---- workgroup d scans row d (rows d, d + wgs, ... when there are fewer workgroups than digits) ---------------
+        for (uint32_t d = wg; d < 256u; d += wgs) {
+            uint32_t carry = 0u;
+            for (uint32_t base = 0; base < wgs; base += (uint32_t)NT) {
+                const uint32_t j = base + (uint32_t)tid;
+                const uint32_t v = j < wgs ? table[(size_t)d * wgs + j] : 0u;
+                uint32_t tot;
+                const uint32_t ex = block_excl_scan_u32<NT>(v, s_wsum, &tot);
+                if (j < wgs) table[(size_t)d * wgs + j] = carry + ex;
+                carry += tot;
+            }
+            if (tid == 0) totals[d] = carry;
+        }
+        if (!grid_barrier(bar, target, wgs, fault)) return;
+        // ---- scatter this workgroup's tiles, carrying per-digit offsets from tile to tile ------------------------------
+        {
+            const uint32_t tot_d = tid < 256 ? totals[tid] : 0u;
+            const uint32_t base_d = block_excl_scan_u32<NT>(tot_d, s_wsum, nullptr);
+            uint32_t carry = tid < 256 ? base_d + table[(size_t)tid * wgs + wg] : 0u;
+            const AosIO<E> io{src, dst};
+            for (uint32_t t = t0; t < t1; ++t) {
+                const uint32_t tb = t * (uint32_t)C::TILE;
+                const uint32_t left = n - tb;
+                sort_scatter_tile<AosIO<E>, 8, NT, K, 1>(io, tb, left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE, n, sb, smem,
+                                                         [&](int, uint32_t c) { const uint32_t g = carry; carry += c; return g; });
+            }
+        }
+        if (!grid_barrier(bar, target, wgs, fault)) return;
+        E* t = src; src = dst; dst = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // C: finish segments in LDS.  A workgroup takes segments blockIdx.x, blockIdx.x + gridDim.x, ...  The segment
 // [seg_start[s], seg_start[s+1]) of `in` is loaded once, sorted on its low `low_bits` bits with up to three stable
 // local passes of at most LBITS bits, and written to the same range of `out` (in == out: in place; everything of a
@@ -37,21 +146,71 @@ namespace adlhip {
 // inputs stay correct, and the host keeps such inputs rare).  In place there is no partner: the segment is left as
 // it is and the device fault word is raised.
 // dyn (may be null): dyn[1] overrides low_bits -- the mid-size sort chooses its digit positions on the device -- and a
-// non-zero dyn[2] makes the kernel return at once (MidDyn::mode).
+// non-zero dyn[2] (MidDyn::mode) sends the workgroups into the cooperative LSD sort below instead.
 // ------------------------------------------------------------------------------------------
+// Keys-only mid-size sort (two launches): the segments are the 256 bucket SLABS msd_bucket_scatter_kernel filled --
+// bucket b occupies slab[b * stride, b * stride + state[b]) -- and go to out[sum of the counts before b ...).
+// state: [0..255] bucket cursors = counts, [256] overflow word, [257] readers-done counter, [258] grid-barrier counter;
+// handle-owned, zero between sorts: the last workgroup to have read it clears it.
+struct SegSlab {
+    uint32_t* state;      // nullptr: ordinary segment list
+    uint32_t stride;
+    uint32_t* host_mode;  // pinned: 1 + overflow flag of this sort, for the host's hint
+    void* partner;        // the n-element scratch array (ping-pong partner of `out` if the cooperative LSD sort has to run)
+};
+
 template <typename E, int NT, int K, int LBITS>
 __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, const uint32_t* __restrict__ seg_start,
                                                           uint32_t num_segments, uint32_t low_bits_arg,
-                                                          const uint32_t* __restrict__ dyn, uint32_t* fault)
+                                                          const uint32_t* __restrict__ dyn, uint32_t* fault, MidCoop coop,
+                                                          SegSlab slab)
 {
-    if (dyn && dyn[2] != 0u) return;                   // mid-size sort: the cooperative LSD kernel takes this input
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_slab[4];
+    uint32_t slab_m = 0u, slab_out = 0u;
+    if (slab.state) {   // one workgroup per bucket: its count, where its output starts, and whether any bucket overflowed
+        static_assert(NT >= 256, "one thread per bucket");
+        uint32_t* s_wsum0 = reinterpret_cast<uint32_t*>(smem);
+        const int t = (int)threadIdx.x;
+        const uint32_t c = t < 256 ? __hip_atomic_load(slab.state + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t ovf = t == 0 ? __hip_atomic_load(slab.state + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t ex = block_excl_scan_u32<NT>(c, s_wsum0, nullptr);
+        const int used = __syncthreads_count(c != 0u);   // buckets in use: 1 = the top byte is constant
+        if (t == (int)blockIdx.x) { s_slab[0] = c; s_slab[1] = ex; }
+        if (t == 0) s_slab[2] = ovf;
+        __syncthreads();
+        slab_m = s_slab[0];
+        slab_out = s_slab[1];
+        const uint32_t overflow = s_slab[2];
+        // everyone has read the state: the last reader clears it for the next sort on this handle
+        if (t == 0) {
+            const uint32_t done = __hip_atomic_fetch_add(slab.state + 257, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_slab[3] = done;
+        }
+        __syncthreads();
+        if (s_slab[3] == gridDim.x - 1u) {
+            for (int i = t; i < 258; i += NT) __hip_atomic_store(slab.state + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // for the host's hints: 1 = fine, 2 = overflow with several buckets in use (skewed keys: the three-launch form would
+            // not fit either), 3 = overflow because the top byte is constant (the three-launch form picks a lower byte)
+            if (t == 0)
+                __hip_atomic_store(slab.host_mode, !overflow ? 1u : (used > 1 ? 2u : 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (overflow) {   // a bucket did not fit its slab: `out` still holds the unsorted input, `in` is its partner
+            coop_lsd_sort<E, NT, K>(out, static_cast<E*>(slab.partner), coop.n, coop.table, coop.totals, coop.bar, fault, smem);
+            return;
+        }
+        __syncthreads();
+    }
+    if (dyn && dyn[2] != 0u) {   // mid-size sort, skewed keys: `out` still holds the unsorted input, `in` is its partner
+        if (coop.table) coop_lsd_sort<E, NT, K>(out, const_cast<E*>(in), coop.n, coop.table, coop.totals, coop.bar, fault, smem);
+        return;
+    }
     constexpr int NW = NT / 64;
     constexpr int CAP = NT * K;
     constexpr int BINS = 1 << LBITS;
     constexpr int BPL = BINS / 64;                     // bins per lane when a wave folds and scans the counts
     static_assert(BPL == 4 || BPL == 8, "256 or 512 bins");
     using F = TileCfg<E, 8, NT, K>;                    // LDS carve of the through-memory path (sort_scatter_tile)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     E* __restrict__ s_elems = reinterpret_cast<E*>(smem);
     uint32_t* __restrict__ s_wcnt = reinterpret_cast<uint32_t*>(smem + sizeof(E) * CAP);            // [NW][BINS]
     uint16_t* __restrict__ s_wpos = reinterpret_cast<uint16_t*>(s_wcnt + NW * BINS);                 // [NW][BINS]
@@ -65,13 +224,13 @@ __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, c
     const int npass = ((int)low_bits + LBITS - 1) / LBITS;   // digits as even as possible: 18 bits, LBITS 9 -> 9 + 9
 
     for (uint32_t seg = blockIdx.x; seg < num_segments; seg += gridDim.x) {
-        const uint32_t begin = seg_start[seg];
-        const uint32_t m = seg_start[seg + 1] - begin;
+        const uint32_t begin = slab.state ? seg * slab.stride : seg_start[seg];
+        const uint32_t m = slab.state ? slab_m : seg_start[seg + 1] - begin;
         if (m == 0u) continue;
         const E* src = in + begin;
-        E* dst = out + begin;
+        E* dst = out + (slab.state ? slab_out : begin);
         if (m > (uint32_t)CAP) {
-            if (in == out) {   // no partner array: never sort wrongly in silence
+            if (in == out || slab.state) {   // no partner array: never sort wrongly in silence
                 if (tid == 0) atomicOr(fault + 1, 0x40000u);   // sticky word
                 continue;
             }
@@ -203,6 +362,39 @@ __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, c
 }
 
 // ------------------------------------------------------------------------------------------
+// Keys-only mid-size sort, pass 1 of 2: MSD scatter on the top byte WITHOUT an up-front histogram and WITHOUT look-back.
+// Equal u32 keys are indistinguishable, so this pass need not be stable across tiles: a tile reserves room for its run
+// of every digit with ONE returning atomic on that bucket's cursor and writes the run into the bucket's slab (bucket b
+// owns slab[b * stride, (b+1) * stride)); in what order tiles arrive does not matter, pass 2 sorts each bucket
+// completely and the result is the one sorted array.  (Pairs need the stable three-launch form above: equal keys must
+// keep their order.)  A bucket that outgrows its slab -- skewed keys, or keys whose top byte is constant -- sets the
+// overflow word; pass 2 then sorts the untouched input with the cooperative LSD sort instead.
+// ------------------------------------------------------------------------------------------
+template <typename E, int NT, int K>
+__global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(const E* __restrict__ src, E* __restrict__ slab, uint32_t* state,
+                                                                uint32_t n, uint32_t stride)
+{
+    using C = TileCfg<E, 8, NT, K>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(state + 258, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // grid-barrier counter of the safety net
+    const uint32_t base = blockIdx.x * (uint32_t)C::TILE;
+    const uint32_t left = n - base;
+    const uint32_t valid = left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE;
+    const uint32_t pads = (uint32_t)C::TILE - valid;   // all-ones pads of a short last tile: counted under digit 255, never stored
+    const AosIO<E> io{src, slab};
+    sort_scatter_tile<AosIO<E>, 8, NT, K, 1>(io, base, valid, 256u * stride, 24, smem, [&](int b, uint32_t c) -> uint32_t {
+        const uint32_t real = c - (b == 255 ? pads : 0u);
+        uint32_t at = 0u;
+        if (real) {
+            at = __hip_atomic_fetch_add(state + b, real, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (at + real > stride) __hip_atomic_fetch_or(state + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return (uint32_t)b * stride + at;
+    });
+}
+
+// ------------------------------------------------------------------------------------------
 // Mid-size sort (16 Ki < n <= 2 Mi keys): THREE launches instead of the 8-12 dependent launches of the per-digit
 // passes, which is what these sizes -- every size of the reference's own test, UnitTest/main.cpp:105 -- pay for
 // (~3 us per kernel boundary; profiles/r1_ncurve.txt).
@@ -211,8 +403,8 @@ __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, c
 //                           bucket), and builds the offset tables of pass 2 and the 257 bucket bounds of pass 3
 //   2. onesweep_chain_kernel one MSD pass on that byte (16 look-back chains = 16 slices of the input), data -> tmp
 //   3. segment_sort_kernel  every bucket finished in LDS on the bytes below, tmp -> data
-// Skewed keys can leave a bucket larger than the LDS tile; its workgroup then sorts it through global memory
-// (segment_sort_kernel): correct for any input, slow for adversarial ones ("sort.mid" = 0 turns the path off).
+// Skewed keys can leave a bucket larger than the LDS tile: mid_prep_kernel then sets MidDyn::mode, pass 2 returns at
+// once and the workgroups of pass 3 run a cooperative 4 x 8-bit LSD sort instead ("sort.mid" = 0 turns the path off).
 // ------------------------------------------------------------------------------------------
 constexpr int kMidChunk = 8192;       // elements per histogram workgroup (two 4 Ki-element tiles of pass 2)
 constexpr int kMidPrepNT = 256;
@@ -349,110 +541,6 @@ __global__ __launch_bounds__(kMidPrepNT) void mid_prep_kernel(const E* __restric
         const uint32_t es = e0 < n ? (uint32_t)e0 : n;
         table->chunk_start[tid] = es;
         table->tile_start[tid] = (es + tile - 1u) / tile;   // slices are whole tiles except the last one
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// The mid-size sort's safety net: ONE launch that does the whole 4 x 8-bit LSD sort with grid-wide barriers between
-// its phases.  It is always enqueued behind passes 2 and 3 and returns at its first instruction unless
-// mid_prep_kernel found a bucket that does not fit the LDS tile (MidDyn::mode = 1: clustered / low-entropy keys).
-// A skewed input therefore costs about 2-3x the per-digit passes instead of one workgroup sorting a huge bucket
-// alone (measured before this existed: 1.5-2.7 ms for 1 Mi clustered keys, profiles/r2_mid_size_distributions.txt),
-// and a friendly one pays one empty launch.  Per pass: every workgroup counts the digits of its run of tiles ->
-// barrier -> workgroup d scans row d of the bucket-major table (the reference's table layout,
-// RadixSort32Kernels.cl:233) -> barrier -> every workgroup scatters its tiles with a per-digit carry -> barrier.
-// All workgroups are resident at once (at most one per CU is needed and each takes ~1/8 of a CU's LDS); every
-// spin is bounded and raises the device fault word when it gives up.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t& target, uint32_t wgs, uint32_t* fault)
-{
-    __shared__ uint32_t ok;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this workgroup's stores leave the XCD's L2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        target += wgs;
-        uint32_t spins = 0u, good = 1u;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins > (1u << 24)) { good = 0u; break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (!good) raise_fault(fault, 0x80000u);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop what this CU's L1 holds of other workgroups' data
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ok = good;
-    }
-    __syncthreads();
-    return ok != 0u;
-}
-
-template <typename E, int NT, int K>
-__global__ __launch_bounds__(NT) void coop_lsd_sort_kernel(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table /*[256][wgs]*/,
-                                                           uint32_t* __restrict__ totals /*[256]*/, uint32_t* bar,
-                                                           const uint32_t* __restrict__ dyn, uint32_t* fault)
-{
-    if (dyn[2] == 0u) return;
-    using C = TileCfg<E, 8, NT, K>;
-    constexpr int NW = NT / 64;
-    static_assert(NT >= 256, "one thread per digit");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* hist = reinterpret_cast<uint32_t*>(smem + C::OFF_WCNT);   // [NW][256]
-    uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + C::OFF_WSUM);
-    const int tid = (int)threadIdx.x;
-    const int w = tid >> 6;
-    const uint32_t wg = blockIdx.x, wgs = gridDim.x;
-    const uint32_t tiles = (n + (uint32_t)C::TILE - 1u) / (uint32_t)C::TILE;
-    const uint32_t per = (tiles + wgs - 1u) / wgs;
-    const uint32_t t0 = wg * per < tiles ? wg * per : tiles;
-    const uint32_t t1 = t0 + per < tiles ? t0 + per : tiles;
-    const uint32_t e0 = t0 * (uint32_t)C::TILE;
-    const uint32_t e1 = (uint64_t)t1 * C::TILE < n ? t1 * (uint32_t)C::TILE : n;
-    uint32_t target = 0u;   // mid_prep_kernel leaves the barrier counter at zero (done[1])
-    E* src = data;
-    E* dst = tmp;
-    for (int sb = 0; sb < 32; sb += 8) {
-        // ---- count the digits of this workgroup's run of tiles --------------------------------------------------------
-        for (int i = tid; i < NW * 256; i += NT) hist[i] = 0u;
-        __syncthreads();
-        for (uint32_t i = e0 + (uint32_t)tid; i < e1; i += (uint32_t)NT)
-            atomicAdd(&hist[w * 256 + (((uint32_t)src[i] >> sb) & 255u)], 1u);
-        __syncthreads();
-        if (tid < 256) {
-            uint32_t c = 0u;
-            for (int i = 0; i < NW; ++i) c += hist[i * 256 + tid];
-            table[(size_t)tid * wgs + wg] = c;
-        }
-        if (!grid_barrier(bar, target, wgs, fault)) return;
-        // ---- workgroup d scans row d (rows d, d + wgs, ... when there are fewer workgroups than digits) ---------------
-        for (uint32_t d = wg; d < 256u; d += wgs) {
-            uint32_t carry = 0u;
-            for (uint32_t base = 0; base < wgs; base += (uint32_t)NT) {
-                const uint32_t j = base + (uint32_t)tid;
-                const uint32_t v = j < wgs ? table[(size_t)d * wgs + j] : 0u;
-                uint32_t tot;
-                const uint32_t ex = block_excl_scan_u32<NT>(v, s_wsum, &tot);
-                if (j < wgs) table[(size_t)d * wgs + j] = carry + ex;
-                carry += tot;
-            }
-            if (tid == 0) totals[d] = carry;
-        }
-        if (!grid_barrier(bar, target, wgs, fault)) return;
-        // ---- scatter this workgroup's tiles, carrying per-digit offsets from tile to tile ------------------------------
-        {
-            const uint32_t tot_d = tid < 256 ? totals[tid] : 0u;
-            const uint32_t base_d = block_excl_scan_u32<NT>(tot_d, s_wsum, nullptr);
-            uint32_t carry = tid < 256 ? base_d + table[(size_t)tid * wgs + wg] : 0u;
-            const AosIO<E> io{src, dst};
-            for (uint32_t t = t0; t < t1; ++t) {
-                const uint32_t tb = t * (uint32_t)C::TILE;
-                const uint32_t left = n - tb;
-                sort_scatter_tile<AosIO<E>, 8, NT, K, 1>(io, tb, left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE, n, sb, smem,
-                                                         [&](int, uint32_t c) { const uint32_t g = carry; carry += c; return g; });
-            }
-        }
-        if (!grid_barrier(bar, target, wgs, fault)) return;
-        E* t = src; src = dst; dst = t;
     }
 }
 

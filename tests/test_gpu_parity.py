@@ -1063,3 +1063,37 @@ def test_sharded_sort_behind_the_c_abi_one_device_group():
         dst.release()
     finally:
         assert lib.adlhip_group_destroy(g) == 0
+
+
+@pytest.mark.parametrize("form", [2, 3], ids=["two-launch-keys", "three-launch"])
+def test_mid_size_sort_forms_on_friendly_and_skewed_keys(dev, form):
+    """The mid-size sort forced into each of its forms ("sort.mid" = 2: unstable MSD pass with bucket cursors + LDS finish, keys
+    only; 3: byte histograms + stable MSD pass + LDS finish) on inputs that fit its buckets and on inputs that do not (the
+    cooperative LSD sort inside pass 2 / 3 takes over): bit-exact either way, pairs stable."""
+    set_algo(dev, (-1, 8, -1))
+    dev.setParam("sort.mid", form)
+    p = Pprims()
+    rng = np.random.RandomState(form)
+    try:
+        for n in (16385, 40000, 262144, 300007, 1 << 20, (1 << 21) - 5):
+            u = rng.randint(0, 2**32, n, dtype=np.uint64)
+            cases = {
+                "uniform": u,
+                "below 2^24": u >> np.uint64(8),
+                "below 2^12": u >> np.uint64(20),
+                "two clusters": np.where(u & np.uint64(1), u >> np.uint64(16), np.uint64(0xffff0000) | (u >> np.uint64(16))),
+                "all equal": np.full(n, 0x01020304, dtype=np.uint64),
+                "sorted": np.sort(u),
+                "one heavy byte": np.where(rng.rand(n) < 0.9, u >> np.uint64(8), u),
+                "top byte only": (u >> np.uint64(24)) << np.uint64(24),
+            }
+            for nm, k in cases.items():
+                k32 = k.astype(np.uint32)
+                assert np.array_equal(gpu_sort_u32(dev, p, k32), oracle.sort_u32(k32)), (nm, n)
+                if n <= (1 << 20):
+                    pairs = (k & np.uint64(0xffffffff)) | (np.arange(n, dtype=np.uint64) << np.uint64(32))
+                    assert np.array_equal(gpu_sort_kv(dev, p, pairs), oracle.sort_kv32(pairs)), (nm, n)
+        DeviceUtils.waitForCompletion(dev)      # no device fault (bounded spins of the grid barrier)
+    finally:
+        dev.setParam("sort.mid", 1)
+        p.close()

@@ -8,12 +8,12 @@ d = DeviceUtils.allocate(); p = Pprims()
 kinds = sys.argv[1:] or ["u32", "kv"]
 for kind in kinds:
     dtype, gen = (np.uint32, 0) if kind == "u32" else (np.uint64, 1)
-    print("%-4s %10s %12s %12s" % (kind, "n", "mid=1 us", "mid=0 us"))
+    print("%-4s %10s %12s %12s %12s" % (kind, "n", "mid=1 us", "mid=3 us", "mid=0 us"))
     for n in [1 << lg for lg in range(10, 23)] + [20000, 100000, 300007, 1000003]:
         reps = 16
         bufs = [Buffer(d, n, dtype) for _ in range(reps)]
         res = []
-        for mid in (1, 0):
+        for mid in (1, 3, 0):
             d.setParam("sort.mid", mid)
             best = 1e9
             for trial in range(5):
@@ -24,6 +24,6 @@ for kind in kinds:
                 sw.stop()
                 best = min(best, sw.getMs() / reps)
             res.append(best * 1e3)
-        print("%-4s %10d %12.1f %12.1f" % ("", n, res[0], res[1]), flush=True)
+        print("%-4s %10d %12.1f %12.1f %12.1f" % ("", n, res[0], res[1], res[2]), flush=True)
         for b in bufs: b.release()
 p.close(); DeviceUtils.deallocate(d)
