@@ -84,7 +84,10 @@ struct adlhip_device {
     int mid_path = 1;         // 16 Ki < n <= 2 Mi: MSD pass + LDS finish (three launches) instead of per-digit passes
     int mid_skip = 0;         // eligible sorts still to be sent down the per-digit passes after a skewed input (see mid_eligible)
     int mid2_skip = 0;        // keys-only sorts still to take the three-launch form after a slab overflow (see mid_sort_keys)
-    int mid_backoff = 32, mid2_backoff = 64;   // how many sorts the next fallback / overflow skips (x8 each time, reset by a success)
+    int mid_backoff = 32, mid2_backoff = 64;
+    int msd2_path = 1;        // 4 Mi < n <= 64 Mi u32 keys: two MSD passes with bucket cursors + LDS finish (msd2_sort)
+    int msd2_skip = 0, msd2_backoff = 32;
+    uint32_t* d_msd2 = nullptr;   // msd2_sort's cursors (256 padded to a line each + 65536) + flag + done counter, allocated on first use   // how many sorts the next fallback / overflow skips (x8 each time, reset by a success)
     // profiling
     std::vector<PendingProf> pending;
     std::vector<hipEvent_t> event_pool;
@@ -661,6 +664,21 @@ int launch_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* s
     });
 }
 
+template <typename E, int K>
+int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* seg_start, size_t num_segments, int low_bits,
+                             const uint32_t* seg_cnt = nullptr, uint32_t in_stride = 0, const uint32_t* gate = nullptr)
+{
+    constexpr int WAVES = 8;
+    auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES>;
+    const size_t lds = (size_t)WAVES * (sizeof(E) * 64 * K + 256 * 4);
+    if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
+    const uint32_t grid = (uint32_t)((num_segments + WAVES - 1) / WAVES);
+    return launch(d, sizeof(E) == 4 ? "segment_sort_wave_u32" : "segment_sort_wave_e64", [&] {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, d->stream, in, out, seg_start, (uint32_t)num_segments,
+                           (uint32_t)low_bits, d->d_fault, seg_cnt, in_stride, gate);
+    });
+}
+
 // largest segment the finishing kernel takes for this element size and number of low bits
 size_t segment_capacity(size_t elem_bytes, int low_bits)
 {
@@ -672,6 +690,10 @@ template <typename E>
 int segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* seg_start, size_t num_segments, size_t max_segment,
                  int low_bits, const uint32_t* dyn)
 {
+    // small segments, at most 16 bits: one wave per segment
+    static const bool no_wave = getenv("ADLHIP_SEGSORT_NO_WAVE") != nullptr;
+    if (!no_wave && low_bits <= 16 && dyn == nullptr && max_segment <= 1280)
+        return launch_wave_segment_sort<E, 20>(d, in, out, seg_start, num_segments, low_bits);
     // tile by the caller's bound on the segment size; the digit width of the local passes by what fits beside the tile
     if (sizeof(E) == 4) {
         if (max_segment <= 4096) return launch_segment_sort<E, 256, 16, 9>(d, in, out, seg_start, num_segments, low_bits, dyn);
@@ -820,16 +842,132 @@ int mid_sort_keys(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, s
     auto ka = adlhip::msd_bucket_scatter_kernel<E, 256, 16>;
     if (ensure_lds(ka, CA::LDS_BYTES)) return ADLHIP_FAILURE;
     const uint32_t tiles = (uint32_t)((n + kMidTile - 1) / kMidTile);
+    adlhip::BucketPass<E> pa;
+    pa.src = data; pa.dst = slab; pa.cursors = state; pa.cursor_shift = 5; pa.src_count_shift = 0; pa.flag = state + 8192;
+    pa.src_counts = nullptr; pa.n = (uint32_t)n; pa.src_stride = 0; pa.tiles_per_bucket = 1; pa.dst_stride = L.stride;
+    pa.dst_total = 256u * L.stride; pa.start_bit = 24; pa.zero_me = state + 8194;
     int rc = launch(d, "mid_bucket_scatter_u32", [&] {
-        hipLaunchKernelGGL(ka, dim3(tiles), dim3(256), CA::LDS_BYTES, d->stream, (const E*)data, slab, state, (uint32_t)n, L.stride);
+        hipLaunchKernelGGL(ka, dim3(tiles), dim3(256), CA::LDS_BYTES, d->stream, pa);
     });
     if (rc) return rc;
     uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
-    const adlhip::MidCoop coop{ctable, ctable + (size_t)256 * 256, state + 258, (uint32_t)n};
+    const adlhip::MidCoop coop{ctable, ctable + (size_t)256 * 256, state + 8194, (uint32_t)n};
     const adlhip::SegSlab sl{state, L.stride, d->h_fault + 10, tmp};
     if (L.stride <= 4096) return launch_segment_sort<E, 256, 16, 8>(d, slab, data, nullptr, 256, 24, nullptr, coop, sl);
     if (L.stride <= 8192) return launch_segment_sort<E, 512, 16, 8>(d, slab, data, nullptr, 256, 24, nullptr, coop, sl);
     return launch_segment_sort<E, 512, 32, 8>(d, slab, data, nullptr, 256, 24, nullptr, coop, sl);
+}
+
+// ---- large keys-only sort: two unstable MSD passes with bucket cursors + LDS finish (hybrid_kernels.hpp "sort.msd2") ------
+constexpr size_t kMsd2Min = size_t(4) << 20;                       // keys; the path works from here ("sort.msd2" = 2) ...
+constexpr size_t kMsd2AutoMin = size_t(6) << 20;                   // ... and is chosen from here (profiles/r2_msd2_size_curve.txt)
+constexpr size_t kMsd2Max = (size_t(1) << 26) + (size_t(1) << 20); // mean segment n / 65536 <= ~1040 of a 1280-key LDS tile
+constexpr uint32_t kMsd2StrideB = 1280;                            // = 64 * 20: the wave kernel's tile
+
+struct Msd2Layout {
+    size_t off_mode, off_cnt, off_off, off_coop, off_slab_a, off_slab_b, total;
+    uint32_t stride_a, tiles_per_bucket;
+};
+
+Msd2Layout msd2_layout(const adlhip_device* d, size_t n)
+{
+    Msd2Layout L;
+    const size_t base = 0;
+    (void)d;
+    L.stride_a = (uint32_t)align_up(n / 256 + n / 8192 + 4096, 64);   // mean bucket + 3 % + 4096
+    L.tiles_per_bucket = (L.stride_a + 16383) / 16384;
+    L.off_mode = base;
+    L.off_cnt = L.off_mode + 256;
+    L.off_off = L.off_cnt + 65536 * 4;
+    L.off_coop = align_up(L.off_off + 65537 * 4, 256);                       // safety net: table [256][256] + 256 totals
+    L.off_slab_a = align_up(L.off_coop + (size_t)256 * 256 * 4 + 1024, 256);
+    L.off_slab_b = align_up(L.off_slab_a + (size_t)256 * L.stride_a * 4, 256);
+    L.total = L.off_slab_b + (size_t)65536 * kMsd2StrideB * 4;
+    return L;
+}
+
+bool msd2_eligible(const adlhip_device* d, size_t n, int sort_bits)
+{
+    return d->sort_algo < 0 && d->msd2_path && sort_bits == 32 && d->rank_mode == 1 && d->digit_bits == 8 && d->tile_variant < 0 &&
+           n > (d->msd2_path == 2 ? kMsd2Min : kMsd2AutoMin) && n <= kMsd2Max;
+}
+
+// Host-side hint, as for the mid-size sort: after a sort whose keys did not fit the slabs (reported into pinned memory by
+// msd2_offsets_kernel, read here without synchronising) this handle's next 32 (256, 2048, 4096) eligible sorts go straight to
+// the per-digit passes; a success resets the count.  Only speed depends on it ("sort.msd2" = 2 forces the path, 0 = off).
+bool msd2_wanted(adlhip_device* d)
+{
+    if (d->msd2_path == 2) return true;
+    if (d->msd2_skip > 0) {
+        --d->msd2_skip;
+        return false;
+    }
+    const uint32_t report = d->h_fault[11];
+    d->h_fault[11] = 0u;
+    if (report == 2u) {
+        d->msd2_skip = d->msd2_backoff;
+        d->msd2_backoff = std::min(d->msd2_backoff * 8, 4096);
+        return false;
+    }
+    if (report == 1u) d->msd2_backoff = 32;
+    return true;
+}
+
+int msd2_sort(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, size_t n)
+{
+    typedef uint32_t E;
+    if (!d->d_msd2) {   // first use on this handle: cursors of both passes + flag + done counter, zero between sorts
+        HIPCHK(hipMalloc(&d->d_msd2, (8192 + 65536 + 64) * 4));
+        HIPCHK(hipMemsetAsync(d->d_msd2, 0, (8192 + 65536 + 64) * 4, d->stream));
+    }
+    uint32_t* cur_a = d->d_msd2;            // 256 cursors, one 128-byte line each
+    uint32_t* cur_b = d->d_msd2 + 8192;     // 65536 cursors, packed (16 atomics each per sort)
+    uint32_t* flag = d->d_msd2 + 8192 + 65536;
+    uint32_t* done = flag + 1;
+    const Msd2Layout L = msd2_layout(d, n);
+    char* wb = reinterpret_cast<char*>(work);
+    uint32_t* mode = reinterpret_cast<uint32_t*>(wb + L.off_mode);
+    uint32_t* seg_cnt = reinterpret_cast<uint32_t*>(wb + L.off_cnt);
+    uint32_t* seg_off = reinterpret_cast<uint32_t*>(wb + L.off_off);
+    E* slab_a = reinterpret_cast<E*>(wb + L.off_slab_a);
+    E* slab_b = reinterpret_cast<E*>(wb + L.off_slab_b);
+    using CT = adlhip::TileCfg<E, 8, 512, 32>;
+    auto kern = adlhip::msd_bucket_scatter_kernel<E, 512, 32>;
+    if (ensure_lds(kern, CT::LDS_BYTES)) return ADLHIP_FAILURE;
+    adlhip::BucketPass<E> pa;   // pass 1: the input, top byte -> 256 bucket slabs
+    pa.src = data; pa.dst = slab_a; pa.cursors = cur_a; pa.cursor_shift = 5; pa.src_count_shift = 0; pa.flag = flag;
+    pa.src_counts = nullptr; pa.n = (uint32_t)n;
+    pa.src_stride = 0; pa.tiles_per_bucket = 1; pa.dst_stride = L.stride_a; pa.dst_total = 256u * L.stride_a; pa.start_bit = 24;
+    pa.zero_me = nullptr;
+    const uint32_t tiles_a = (uint32_t)((n + CT::TILE - 1) / CT::TILE);
+    int rc = launch(d, "msd2_pass1_u32", [&] { hipLaunchKernelGGL(kern, dim3(tiles_a), dim3(512), CT::LDS_BYTES, d->stream, pa); });
+    if (rc) return rc;
+    adlhip::BucketPass<E> pb;   // pass 2: every bucket, second byte -> 65536 segment slabs
+    pb.src = slab_a; pb.dst = slab_b; pb.cursors = cur_b; pb.cursor_shift = 0; pb.src_count_shift = 5; pb.flag = flag;
+    pb.src_counts = cur_a; pb.n = (uint32_t)n;
+    pb.src_stride = L.stride_a; pb.tiles_per_bucket = L.tiles_per_bucket; pb.dst_stride = kMsd2StrideB;
+    pb.dst_total = 65536u * kMsd2StrideB; pb.start_bit = 16; pb.zero_me = nullptr;
+    rc = launch(d, "msd2_pass2_u32", [&] {
+        hipLaunchKernelGGL(kern, dim3(256 * L.tiles_per_bucket), dim3(512), CT::LDS_BYTES, d->stream, pb);
+    });
+    if (rc) return rc;
+    uint32_t* bar = done + 1;
+    rc = launch(d, "msd2_offsets", [&] {
+        hipLaunchKernelGGL(adlhip::msd2_offsets_kernel, dim3(256), dim3(256), 0, d->stream, cur_a, cur_b, flag, done, bar, seg_cnt, seg_off,
+                           mode, d->h_fault + 11, (uint32_t)n);
+    });
+    if (rc) return rc;
+    rc = launch_wave_segment_sort<E, 20>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, kMsd2StrideB, mode);
+    if (rc) return rc;
+    // the safety net: ONE launch that returns at its first instruction unless the mode word is set, in which case its 256
+    // resident workgroups sort the untouched input with the cooperative LSD sort (hybrid_kernels.hpp coop_lsd_sort)
+    auto coop = adlhip::coop_lsd_sort_kernel<E, 512, 32>;
+    if (ensure_lds(coop, CT::LDS_BYTES)) return ADLHIP_FAILURE;
+    uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
+    return launch(d, "msd2_coop_lsd_u32", [&] {
+        hipLaunchKernelGGL(coop, dim3(256), dim3(512), CT::LDS_BYTES, d->stream, data, tmp, (uint32_t)n, ctable, ctable + 256 * 256, bar,
+                           (const uint32_t*)mode, d->d_fault);
+    });
 }
 
 size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)
@@ -840,7 +978,9 @@ size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)
     else if (elem_kind == ADLHIP_ELEM_SOA32) b = onesweep_layout(d, n, max_passes_for(d, 64), buf_tile<SoaBuf>(d, n)).total;
     else b = onesweep_layout(d, n, max_passes_for(d, 64), buf_tile<AosBuf<uint64_t>>(d, n)).total;   // as onesweep_sort<Buf>()
     const size_t c = n <= kMidMaxU32 ? mid_layout(n).total : mid_layout(kMidMaxU32).total;   // mid-size sort (monotone in n)
-    return std::max(std::max(a, b), c);
+    size_t e = 0;   // large keys-only sort: slabs behind the one-sweep layout (monotone in n up to its limit)
+    if (elem_kind == ADLHIP_ELEM_U32 && n > kMsd2Min) e = msd2_layout(d, std::min(n, kMsd2Max)).total;
+    return std::max(std::max(a, b), std::max(c, e));
 }
 
 // Work bytes that suffice for EVERY n' <= n with the current knobs: the requirement of one n is not monotone (a smaller
@@ -902,6 +1042,9 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
             if (form == 2) return mid_sort_keys(d, data, tmp, work, n);   // two launches
         }
         if (form == 3) return mid_sort<E>(d, data, tmp, work, n);         // three launches
+    }
+    if constexpr (sizeof(E) == 4) {
+        if (msd2_eligible(d, n, sort_bits) && msd2_wanted(d)) return msd2_sort(d, data, tmp, work, n);
     }
     return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, n, plan);
 }
@@ -1057,8 +1200,8 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         return fail("cannot allocate the fault word");
     }
     memset(d->h_fault, 0, 64);
-    if (hipMalloc(&d->d_mid_hist, (16 * 1024 + 512) * 4) != hipSuccess ||
-        hipMemsetAsync(d->d_mid_hist, 0, (16 * 1024 + 512) * 4, d->stream) != hipSuccess) {
+    if (hipMalloc(&d->d_mid_hist, (16 * 1024 + 8192 + 64) * 4) != hipSuccess ||
+        hipMemsetAsync(d->d_mid_hist, 0, (16 * 1024 + 8192 + 64) * 4, d->stream) != hipSuccess) {
         if (d->d_mid_hist) hipFree(d->d_mid_hist);
         hipFree(d->d_fault);
         hipHostFree(d->h_fault);
@@ -1075,6 +1218,7 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
     if (const char* t = getenv("ADLHIP_SORT_TILE")) { int v = atoi(t); if (v >= -1 && v < kNumVariants) d->tile_variant = v; }
     if (const char* r = getenv("ADLHIP_SORT_RANK")) d->rank_mode = (atoi(r) && d->lds_ordered) ? 1 : 0;
     if (const char* m = getenv("ADLHIP_SORT_MID")) d->mid_path = atoi(m) ? 1 : 0;
+    if (const char* m = getenv("ADLHIP_SORT_MSD2")) { int v = atoi(m); if (v >= 0 && v <= 2) d->msd2_path = v; }
     if (const char* b = getenv("ADLHIP_DIGIT_BITS")) { int v = atoi(b); d->digit_bits = (v == 4 || v == 7) ? v : 8; }
     *out = d;
     return ADLHIP_SUCCESS;
@@ -1100,6 +1244,7 @@ int adlhip_device_destroy(adlhip_device* d)
     for (auto e : d->event_pool) hipEventDestroy(e);
     if (d->fault_snap) hipEventDestroy(d->fault_snap);
     hipFree(d->d_mid_hist);
+    if (d->d_msd2) hipFree(d->d_msd2);
     hipFree(d->d_fault);
     hipHostFree(d->h_fault);
     if (d->own_stream) hipStreamDestroy(d->stream);
@@ -1511,6 +1656,9 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
     } else if (!strcmp(name, "sort.mid")) {
         if (value < 0 || value > 3) return fail("sort.mid must be 0 (off), 1 (on), 2 (keys: always the two-launch form) or 3 (always the three-launch form)");
         d->mid_path = value;
+    } else if (!strcmp(name, "sort.msd2")) {
+        if (value < 0 || value > 2) return fail("sort.msd2 must be 0 (off), 1 (on) or 2 (always, whatever the hints say)");
+        d->msd2_path = value;
     } else if (!strcmp(name, "sort.rank")) {
         if (value != 0 && value != 1) return fail("sort.rank must be 0 or 1");
         if (value == 1 && !d->lds_ordered) return fail("sort.rank = 1 needs lane-ordered DS atomics; the device self-test failed");
@@ -1533,6 +1681,7 @@ int adlhip_get_param(adlhip_device* d, const char* name, int* value)
     else if (!strcmp(name, "sort.tile")) *value = d->tile_variant;
     else if (!strcmp(name, "sort.rank")) *value = d->rank_mode;
     else if (!strcmp(name, "sort.mid")) *value = d->mid_path;
+    else if (!strcmp(name, "sort.msd2")) *value = d->msd2_path;
     else if (!strcmp(name, "sort.lds_ordered")) *value = d->lds_ordered;
     else if (!strcmp(name, "profile")) *value = d->profile;
     else return fail("unknown parameter '%s'", name);

@@ -129,6 +129,16 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
     }
 }
 
+template <typename E, int NT, int K>
+__global__ __launch_bounds__(NT) void coop_lsd_sort_kernel(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table,
+                                                           uint32_t* __restrict__ totals, uint32_t* bar,
+                                                           const uint32_t* __restrict__ gate, uint32_t* fault)
+{
+    if (*gate == 0u) return;   // the large keys-only sort fitted its slabs: nothing to do
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    coop_lsd_sort<E, NT, K>(data, tmp, n, table, totals, bar, fault, smem);
+}
+
 // ------------------------------------------------------------------------------------------
 // C: finish segments in LDS.  A workgroup takes segments blockIdx.x, blockIdx.x + gridDim.x, ...  The segment
 // [seg_start[s], seg_start[s+1]) of `in` is loaded once, sorted on its low `low_bits` bits with up to three stable
@@ -150,8 +160,8 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
 // ------------------------------------------------------------------------------------------
 // Keys-only mid-size sort (two launches): the segments are the 256 bucket SLABS msd_bucket_scatter_kernel filled --
 // bucket b occupies slab[b * stride, b * stride + state[b]) -- and go to out[sum of the counts before b ...).
-// state: [0..255] bucket cursors = counts, [256] overflow word, [257] readers-done counter, [258] grid-barrier counter;
-// handle-owned, zero between sorts: the last workgroup to have read it clears it.
+// state: bucket cursors = counts at [32 * b] (one 128-byte line each), [8192] overflow word, [8193] readers-done counter,
+// [8194] grid-barrier counter; handle-owned, zero between sorts: the last workgroup to have read it clears it.
 struct SegSlab {
     uint32_t* state;      // nullptr: ordinary segment list
     uint32_t stride;
@@ -172,8 +182,8 @@ __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, c
         static_assert(NT >= 256, "one thread per bucket");
         uint32_t* s_wsum0 = reinterpret_cast<uint32_t*>(smem);
         const int t = (int)threadIdx.x;
-        const uint32_t c = t < 256 ? __hip_atomic_load(slab.state + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        const uint32_t ovf = t == 0 ? __hip_atomic_load(slab.state + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t c = t < 256 ? __hip_atomic_load(slab.state + 32 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t ovf = t == 0 ? __hip_atomic_load(slab.state + 8192, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         const uint32_t ex = block_excl_scan_u32<NT>(c, s_wsum0, nullptr);
         const int used = __syncthreads_count(c != 0u);   // buckets in use: 1 = the top byte is constant
         if (t == (int)blockIdx.x) { s_slab[0] = c; s_slab[1] = ex; }
@@ -184,12 +194,13 @@ __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, c
         const uint32_t overflow = s_slab[2];
         // everyone has read the state: the last reader clears it for the next sort on this handle
         if (t == 0) {
-            const uint32_t done = __hip_atomic_fetch_add(slab.state + 257, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t done = __hip_atomic_fetch_add(slab.state + 8193, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_slab[3] = done;
         }
         __syncthreads();
         if (s_slab[3] == gridDim.x - 1u) {
-            for (int i = t; i < 258; i += NT) __hip_atomic_store(slab.state + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = t; i < 256; i += NT) __hip_atomic_store(slab.state + 32 * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < 2) __hip_atomic_store(slab.state + 8192 + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // for the host's hints: 1 = fine, 2 = overflow with several buckets in use (skewed keys: the three-launch form would
             // not fit either), 3 = overflow because the top byte is constant (the three-launch form picks a lower byte)
             if (t == 0)
@@ -362,6 +373,91 @@ __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, c
 }
 
 // ------------------------------------------------------------------------------------------
+// Small segments (at most 64*K elements, at most 16 low bits): ONE WAVE per segment, no workgroup barrier anywhere.
+// The segment sits in the wave's registers (lane l, item j <-> element j*64 + l) and in the wave's private slice of
+// LDS.  Per 8-bit local pass: every element bumps its bin (DS add), the lanes turn the 256 counts into bin starts
+// (4 bins per lane + one DPP scan), every element fetches its slot with a RETURNING DS add on its bin -- issue order =
+// item order and colliding lanes in lane order, so the slots are handed out stably (radix_kernels.hpp rank_in_wave) --
+// and goes to LDS there; the tile comes back in order.  DS operations of one wave execute in issue order, so the
+// phases need no barrier, and nothing but the elements lives in registers across them (the first wave-per-segment
+// kernel kept ranks and predicates too, 165-175 VGPRs, and ran at two or three waves per SIMD).
+// ------------------------------------------------------------------------------------------
+// Slab form (seg_cnt != nullptr; the large keys-only sort): segment s is in[s * in_stride, + seg_cnt[s]) and goes to
+// out[seg_start[s] ...); the kernel returns at once when *gate is non-zero.
+template <typename E, int K, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* in, E* out, const uint32_t* __restrict__ seg_start,
+                                                                        uint32_t num_segments, uint32_t low_bits, uint32_t* fault,
+                                                                        const uint32_t* __restrict__ seg_cnt, uint32_t in_stride,
+                                                                        const uint32_t* __restrict__ gate)
+{
+    if (gate && *gate != 0u) return;
+    constexpr int CAP = 64 * K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = (int)threadIdx.x & 63;
+    const int w = (int)threadIdx.x >> 6;
+    unsigned char* mine = smem + (size_t)w * (sizeof(E) * CAP + 256 * 4);
+    E* __restrict__ buf = reinterpret_cast<E*>(mine);
+    uint32_t* __restrict__ cnt = reinterpret_cast<uint32_t*>(mine + sizeof(E) * CAP);
+
+    const uint32_t seg = blockIdx.x * (uint32_t)WAVES + (uint32_t)w;
+    if (seg >= num_segments) return;
+    const uint32_t begin = seg_start[seg];
+    const uint32_t m = seg_cnt ? seg_cnt[seg] : seg_start[seg + 1] - begin;
+    if (m == 0u) return;
+    if (m > (uint32_t)CAP || low_bits > 16u) {   // never sort wrongly in silence
+        if (lane == 0) atomicOr(fault + 1, 0x40000u);
+        return;
+    }
+    const E* src = in + (seg_cnt ? (size_t)seg * in_stride : (size_t)begin);
+    E* dst = out + begin;
+    const int keff = (int)((m + 63u) >> 6);
+    const int rem = (int)m - lane;   // item j of this lane exists iff j*64 < rem
+    E e[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (j < keff) e[j] = (j * 64 < rem) ? src[j * 64 + lane] : E(0);
+
+    const int npass = low_bits > 8u ? 2 : 1;
+    int sb = 0;
+    for (int p = 0; p < npass; ++p) {
+        const int nb = p + 1 < npass ? ((int)low_bits + 1) / 2 : (int)low_bits - sb;
+        const uint32_t mask = (1u << nb) - 1u;
+        auto digit = [&](E x) -> uint32_t { return ((uint32_t)x >> sb) & mask; };
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(cnt + 4 * lane) = z;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j < keff && j * 64 < rem) __hip_atomic_fetch_add(&cnt[digit(e[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        {   // counts -> bin starts
+            const u32x4 c = *reinterpret_cast<const u32x4*>(cnt + 4 * lane);
+            const uint32_t s4 = c.x + c.y + c.z + c.w;
+            const uint32_t ex = wave_incl_scan_u32(s4) - s4;
+            u32x4 o;
+            o.x = ex;
+            o.y = ex + c.x;
+            o.z = o.y + c.y;
+            o.w = o.z + c.z;
+            *reinterpret_cast<u32x4*>(cnt + 4 * lane) = o;
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j < keff && j * 64 < rem) {
+                const uint32_t pos = __hip_atomic_fetch_add(&cnt[digit(e[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                buf[pos] = e[j];
+            }
+        if (p + 1 < npass) {
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if (j < keff && j * 64 < rem) e[j] = buf[j * 64 + lane];
+        }
+        sb += nb;
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (j < keff && j * 64 < rem) dst[j * 64 + lane] = buf[j * 64 + lane];
+}
+
+// ------------------------------------------------------------------------------------------
 // Keys-only mid-size sort, pass 1 of 2: MSD scatter on the top byte WITHOUT an up-front histogram and WITHOUT look-back.
 // Equal u32 keys are indistinguishable, so this pass need not be stable across tiles: a tile reserves room for its run
 // of every digit with ONE returning atomic on that bucket's cursor and writes the run into the bucket's slab (bucket b
@@ -370,28 +466,207 @@ __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, c
 // keep their order.)  A bucket that outgrows its slab -- skewed keys, or keys whose top byte is constant -- sets the
 // overflow word; pass 2 then sorts the untouched input with the cooperative LSD sort instead.
 // ------------------------------------------------------------------------------------------
+// One kernel serves the single MSD pass of the mid-size sort (linear input) and both MSD passes of the large keys-only sort
+// (the second pass reads the buckets of the first: workgroup -> (source bucket, tile inside it), tiles beyond the bucket's
+// count return at once; its cursors are indexed (source bucket, digit)).
+template <typename E>
+struct BucketPass {
+    const E* src;
+    E* dst;
+    uint32_t* cursors;            // [source buckets][256] << cursor_shift, zero on entry
+    uint32_t cursor_shift;        // log2 of the words between two cursors: 5 = one 128-byte line each.  The 256 cursors of a
+                                  // pass over ONE array take an atomic from every tile; packed into 8 lines they queue on 8
+                                  // atomic units (pass 1 of the large sort: 0.33 ms instead of 0.13)
+    uint32_t src_count_shift;     // the same for src_counts
+    uint32_t* flag;               // set when a run does not fit its destination slab
+    const uint32_t* src_counts;   // nullptr: the source is ONE array of n elements; else element counts of the source buckets
+    uint32_t n;
+    uint32_t src_stride;          // elements between two source buckets
+    uint32_t tiles_per_bucket;    // tiles a source bucket can hold
+    uint32_t dst_stride;          // elements per destination slab
+    uint32_t dst_total;           // elements of the whole destination array
+    int start_bit;
+    uint32_t* zero_me;            // one word the first workgroup clears (the safety net's barrier counter), or nullptr
+};
+
+// The tile body is the one-sweep pass's (onesweep_kernels.hpp onesweep_chain_kernel) without its ticket, status rows and
+// look-back: load (wave-striped) -> rank (returning DS atomics) | barrier | every wave folds the counts and writes its own
+// 16-bit positions; wave 0 reserves the tile's 256 runs with returning atomics on the bucket cursors while all waves
+// scatter into LDS | barrier | write-out, consecutive lanes to consecutive addresses of a run.
 template <typename E, int NT, int K>
-__global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(const E* __restrict__ src, E* __restrict__ slab, uint32_t* state,
-                                                                uint32_t n, uint32_t stride)
+__global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
 {
     using C = TileCfg<E, 8, NT, K>;
+    typedef AosIO<E> IO;
+    constexpr int BINS = 256;
+    constexpr int NW = C::NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(state + 258, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // grid-barrier counter of the safety net
-    const uint32_t base = blockIdx.x * (uint32_t)C::TILE;
-    const uint32_t left = n - base;
-    const uint32_t valid = left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE;
-    const uint32_t pads = (uint32_t)C::TILE - valid;   // all-ones pads of a short last tile: counted under digit 255, never stored
-    const AosIO<E> io{src, slab};
-    sort_scatter_tile<AosIO<E>, 8, NT, K, 1>(io, base, valid, 256u * stride, 24, smem, [&](int b, uint32_t c) -> uint32_t {
-        const uint32_t real = c - (b == 255 ? pads : 0u);
-        uint32_t at = 0u;
-        if (real) {
-            at = __hip_atomic_fetch_add(state + b, real, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (at + real > stride) __hip_atomic_fetch_or(state + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    E* __restrict__ s_elems = reinterpret_cast<E*>(smem + C::OFF_ELEMS);
+    uint32_t* __restrict__ s_wcnt = reinterpret_cast<uint32_t*>(smem + C::OFF_WCNT);   // [NW][BINS]
+    uint32_t* __restrict__ s_goff = reinterpret_cast<uint32_t*>(smem + C::OFF_GOFF);   // [BINS]
+    if (a.zero_me && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.zero_me, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t base, valid, cursor_base = 0u;
+    if (a.src_counts == nullptr) {
+        base = blockIdx.x * (uint32_t)C::TILE;
+        const uint32_t left = a.n - base;
+        valid = left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE;
+    } else {
+        const uint32_t b = blockIdx.x / a.tiles_per_bucket, t = blockIdx.x % a.tiles_per_bucket;
+        const uint32_t cnt = a.src_counts[b << a.src_count_shift];
+        const uint32_t off = t * (uint32_t)C::TILE;
+        if (off >= cnt || off >= a.src_stride) return;      // nothing of this bucket in this tile (or the bucket overflowed)
+        const uint32_t room = (cnt < a.src_stride ? cnt : a.src_stride) - off;
+        base = b * a.src_stride + off;
+        valid = room < (uint32_t)C::TILE ? room : (uint32_t)C::TILE;
+        cursor_base = b * 256u;
+    }
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int start_bit = a.start_bit;
+    uint32_t* my_wcnt = s_wcnt + w * BINS;
+    const IO io{a.src, a.dst};
+    const bool scaled = dst_fits32<IO>(a.dst_total);
+
+    // ---- load, wave-striped; slots beyond `valid` are all-ones pads (digit 255, highest tile positions, never stored) ----
+    const uint32_t wbase = (uint32_t)(w * 64 * K + lane);
+    E e[K];
+    {
+        const typename IO::Cursor p = io.cursor((size_t)base + wbase);
+        if (valid == (uint32_t)C::TILE) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) e[j] = p.at(j * 64);
+        } else {
+            const int rem = (int)valid - (int)wbase;
+#pragma unroll
+            for (int j = 0; j < K; ++j) e[j] = (j * 64 < rem) ? p.at(j * 64) : ~E(0);
         }
-        return (uint32_t)b * stride + at;
-    });
+    }
+    // ---- rank ---------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int b = lane; b < BINS; b += 64) my_wcnt[b] = 0u;
+    uint32_t rnk2[(K + 1) / 2];
+    {
+        uint32_t rnk[K];
+        rank_in_wave<E, 8, K, 1>(e, rnk, my_wcnt, start_bit);
+#pragma unroll
+        for (int j = 0; j < K; j += 2) rnk2[j >> 1] = rnk[j] | ((j + 1 < K ? rnk[j + 1] : 0u) << 16);
+    }
+#pragma unroll
+    for (int j = 0; j < (K + 1) / 2; ++j) asm volatile("" : "+v"(rnk2[j]));
+#pragma unroll
+    for (int j = 0; j < K; ++j) asm volatile("" : "+v"(e[j]));
+    __syncthreads();
+    // ---- every wave: counts of all waves for its lanes' digits -> tile offsets -> its own (wave, digit) positions -------------
+    u32x4 cnt4 = {0u, 0u, 0u, 0u};
+    u32x4 toff4 = {0u, 0u, 0u, 0u};
+    uint16_t* __restrict__ my_wpos = reinterpret_cast<uint16_t*>(smem + C::OFF_WPOS) + w * BINS;
+    {
+        u32x4 pre4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const u32x4 r = *reinterpret_cast<const u32x4*>(s_wcnt + i * BINS + 4 * lane);
+            cnt4 += r;
+            if (i < w) pre4 += r;
+        }
+        const uint32_t s4 = cnt4.x + cnt4.y + cnt4.z + cnt4.w;
+        const uint32_t ex = wave_incl_scan_u32(s4) - s4;
+        toff4.x = ex;
+        toff4.y = ex + cnt4.x;
+        toff4.z = toff4.y + cnt4.y;
+        toff4.w = toff4.z + cnt4.z;
+        const u32x4 p4 = toff4 + pre4;
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 packed = {p4.x | (p4.y << 16), p4.z | (p4.w << 16)};
+        *reinterpret_cast<u32x2*>(my_wpos + 4 * lane) = packed;
+    }
+    // ---- wave 0: reserve room for the tile's runs (requested now, consumed after the scatter) -----------------------------------
+    u32x4 at4 = {0u, 0u, 0u, 0u};
+    u32x4 real4 = cnt4;
+    if (w == 0) {
+        if (lane == 63) real4.w -= (uint32_t)C::TILE - valid;   // the pads sit under digit 255
+        uint32_t* cur = a.cursors + ((size_t)(cursor_base + 4u * (uint32_t)lane) << a.cursor_shift);
+        const size_t step = (size_t)1 << a.cursor_shift;
+        if (real4.x) at4.x = __hip_atomic_fetch_add(cur + 0 * step, real4.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (real4.y) at4.y = __hip_atomic_fetch_add(cur + 1 * step, real4.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (real4.z) at4.z = __hip_atomic_fetch_add(cur + 2 * step, real4.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (real4.w) at4.w = __hip_atomic_fetch_add(cur + 3 * step, real4.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- scatter into tile-sorted order ---------------------------------------------------------------------------------------------
+    {
+        constexpr int CH = K < 8 ? K : 8;
+#pragma unroll
+        for (int j0 = 0; j0 < K; j0 += CH) {
+            uint32_t pos[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) pos[j] = my_wpos[digit_of<8>(e[(j0 + j < K) ? j0 + j : K - 1], start_bit)];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                if (j0 + j < K) {
+                    const uint32_t r = (rnk2[(j0 + j) >> 1] >> (16 * ((j0 + j) & 1))) & 0xffffu;
+                    s_elems[pos[j] + r] = e[j0 + j];
+                }
+            }
+        }
+    }
+    if (w == 0) {
+        const bool over = (at4.x + real4.x > a.dst_stride) | (at4.y + real4.y > a.dst_stride) | (at4.z + real4.z > a.dst_stride) |
+                          (at4.w + real4.w > a.dst_stride);
+        if (over) __hip_atomic_fetch_or(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t d0 = cursor_base + 4u * (uint32_t)lane;
+        u32x4 go;   // destination index = goff[digit] + tile position
+        go.x = (d0 + 0u) * a.dst_stride + at4.x - toff4.x;
+        go.y = (d0 + 1u) * a.dst_stride + at4.y - toff4.y;
+        go.z = (d0 + 2u) * a.dst_stride + at4.z - toff4.z;
+        go.w = (d0 + 3u) * a.dst_stride + at4.w - toff4.w;
+        *reinterpret_cast<u32x4*>(s_goff + 4 * lane) = scaled ? go * (uint32_t)IO::kStoreScale : go;
+    }
+    __syncthreads();
+    write_out_tile<IO, 8, NT, K, ADLHIP_WRITE_UNROLL>(io, s_elems, s_goff, valid, a.dst_total, start_bit, scaled);
+}
+
+// ------------------------------------------------------------------------------------------
+// Large keys-only sort ("sort.msd2", 4 Mi < n <= 64 Mi u32 keys): TWO unstable MSD passes with bucket cursors (top byte, then
+// second byte inside every bucket: 65536 segments of n / 65536 keys) and ONE LDS finish (wave_segment_sort_kernel on the low
+// 16 bits).  No histogram kernel, no look-back, 6 sweeps of the data instead of 9.  msd2_offsets_kernel sits between the
+// second pass and the finish: workgroup b turns bucket b's 256 cursors into output offsets (bucket base = scan of the first
+// pass's cursors), saves the counts for the finish, clears the cursors for the next sort (they belong to the device handle),
+// and the last workgroup publishes the mode word: 0 = every run fitted its slab; else 1 -- the finish returns at once and
+// coop_lsd_sort_kernel, one launch that is always enqueued behind it and returns at its first instruction while the word is 0,
+// sorts the untouched input (slowly: it is the safety net; the host's hint keeps such inputs off this path).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, uint32_t* cursors_b, uint32_t* flag, uint32_t* done,
+                                                           uint32_t* bar, uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_off,
+                                                           uint32_t* __restrict__ mode, uint32_t* host_mode, uint32_t n)
+{
+    __shared__ uint32_t s_wsum[256 / 64 + 1];
+    __shared__ uint32_t s_misc[4];
+    const int t = (int)threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    const uint32_t ca = __hip_atomic_load(cursors_a + 32 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one line per cursor
+    const uint32_t exa = block_excl_scan_u32<256>(ca, s_wsum, nullptr);
+    if (t == (int)b) s_misc[0] = exa;
+    const uint32_t cb = __hip_atomic_load(cursors_b + b * 256u + (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t exb = block_excl_scan_u32<256>(cb, s_wsum, nullptr);
+    __syncthreads();
+    seg_cnt[b * 256u + (uint32_t)t] = cb;
+    seg_off[b * 256u + (uint32_t)t] = s_misc[0] + exb;
+    __hip_atomic_store(cursors_b + b * 256u + (uint32_t)t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the first pass's cursors are read by every workgroup: the last one to have read them clears them and publishes the mode
+    if (t == 0) s_misc[1] = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_misc[1] == gridDim.x - 1u) {
+        __hip_atomic_store(cursors_a + 32 * t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) {
+            const uint32_t f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *mode = f ? 1u : 0u;
+            seg_off[65536] = n;
+            __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // grid-barrier counter of the safety net
+            __hip_atomic_store(host_mode, 1u + (f ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1097,3 +1097,38 @@ def test_mid_size_sort_forms_on_friendly_and_skewed_keys(dev, form):
     finally:
         dev.setParam("sort.mid", 1)
         p.close()
+
+
+def test_large_keys_only_sort_two_msd_passes_and_lds_finish(dev):
+    """"sort.msd2" forced on: two unstable MSD passes with bucket cursors + the wave-per-segment LDS finish, for sizes across its
+    range, on keys that fit its slabs and on keys that do not (the mode word then lets the cooperative LSD sort, one launch that is
+    always enqueued behind it, sort the untouched input).  Bit-exact against the oracle either way."""
+    set_algo(dev, (-1, 8, -1))
+    dev.setParam("sort.msd2", 2)
+    p = Pprims()
+    try:
+        for n in ((1 << 22) + 3, 5000011, 1 << 24, 1 << 26, (1 << 26) + 999999):
+            k = oracle.keys_u32(n, seed=n & 0xff)
+            assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), ("uniform", n)
+        n = (1 << 24) + 77
+        u = oracle.keys_u32(n, seed=9)
+        skewed = {
+            "below 2^24": u >> np.uint32(8),
+            "one heavy top byte": np.where(np.arange(n) % 10 != 0, u >> np.uint32(8), u).astype(np.uint32),
+            "second byte constant": u & np.uint32(0xff00ffff),
+            "all equal": np.full(n, 0xdeadbeef, dtype=np.uint32),
+            "sorted": np.sort(u),
+        }
+        for nm, k in skewed.items():
+            assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), nm
+        k = oracle.keys_u32(1 << 26, seed=3) >> np.uint32(8)   # the safety net at the top of the range
+        assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), "below 2^24 at 64Mi"
+        DeviceUtils.waitForCompletion(dev)
+        # and the automatic choice (hints included) stays correct when friendly and skewed inputs alternate
+        dev.setParam("sort.msd2", 1)
+        for i in range(6):
+            k = oracle.keys_u32(n, seed=20 + i) if i % 2 == 0 else (oracle.keys_u32(n, seed=20 + i) >> np.uint32(9))
+            assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), i
+    finally:
+        dev.setParam("sort.msd2", 1)
+        p.close()
