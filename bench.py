@@ -17,7 +17,8 @@ Every step sorts its OWN pre-generated random buffer (K + W buffers of 256 MiB a
 device before the timed region), so no step sees pre-sorted data and no restore copy is timed.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline     : dominant kernel (the per-digit sort+scatter pass), ALGORITHMIC bytes per launch =
+  roofline     : dominant kernel (the pass that sorts a tile by one digit and scatters it: the MSD bucket pass of the
+                 large keys-only sort, the one-sweep pass otherwise), ALGORITHMIC bytes per launch =
                  2*n*E (read n*E + write n*E) / its average launch duration,
                  measured here with hipEvents on the library's own stream in a second, profiled loop
                  over the same inputs (toggleProfiling brackets every launch with an event pair).
@@ -227,8 +228,16 @@ def main():
         info_name = d.getDeviceName()
         DeviceUtils.deallocate(d)
 
-        scatter = {k: v for k, v in prof.items() if k.startswith(("onesweep_", "scatter_"))}
-        dom_name, (dom_launches, dom_ms) = max(scatter.items(), key=lambda kv: kv[1][1])
+        # the kernels that move the whole array once (read n*E + write n*E per launch), grouped by KERNEL as rocprofv3 sees
+        # them: the two MSD bucket passes of the large keys-only sort are two launches of one kernel
+        groups = {}
+        for k, v in prof.items():
+            if k.startswith(("onesweep_", "scatter_", "segment_sort")):
+                groups[k] = (v[0], v[1])
+            elif k.startswith("msd2_pass"):
+                g = groups.get("msd2_pass_u32", (0, 0.0))
+                groups["msd2_pass_u32"] = (g[0] + v[0], g[1] + v[1])
+        dom_name, (dom_launches, dom_ms) = max(groups.items(), key=lambda kv: kv[1][1])
         dom_avg_s = dom_ms / dom_launches * 1e-3
         achieved = 2.0 * n * ELEM_BYTES / dom_avg_s / 1e9
         # HBM traffic per launch from PMC counters: collected in separate rocprofv3 --pmc passes of this same
@@ -255,15 +264,17 @@ def main():
         out["device"] = info_name
         out["verified_vs_oracle"] = verified
         out["event_ms_per_step"] = ev_ms / K
-        # whole sort on the bytes it really moves: one histogram read + (read + write) per global pass
-        passes = max(1, round(sum(v[0] for k, v in prof.items() if k.startswith(("onesweep_", "scatter_", "segment_sort"))) / K))
-        moved = ELEM_BYTES * (1 + 2 * passes)
-        out["whole_sort"] = {"global_passes": passes, "bytes_moved_per_key": moved,
+        # whole sort on the bytes it really moves: one histogram read (if the path has one) + (read + write) per global pass
+        passes = max(1, round(sum(v[0] for v in groups.values()) / K))
+        hist_reads = 1 if any(k.startswith(("os_hist_", "count_", "mid_prep")) for k in prof) else 0
+        moved = ELEM_BYTES * (hist_reads + 2 * passes)
+        out["whole_sort"] = {"global_passes": passes, "histogram_reads": hist_reads, "bytes_moved_per_key": moved,
                              "achieved_GBps": n * moved / (ev_ms / K * 1e-3) / 1e9,
                              "frac_of_peak": n * moved / (ev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS}
         parallelism = "1 GPU"
         workload = "Key-only RadixSort32, %d uniform-random u32 keys (splitmix64 hi32, seed 123+step), 1xMI355X, in place" % n
-        algo_name = {0: "onesweep", 1: "three-kernel", -1: "auto (one-sweep at this size)"}.get(algo, str(algo))
+        auto = "auto (two MSD bucket passes + LDS finish at this size)" if "msd2_pass1_u32" in prof else "auto (one-sweep at this size)"
+        algo_name = {0: "onesweep", 1: "three-kernel", -1: auto}.get(algo, str(algo))
         cfg_extra = {"sort_algo": algo_name, "digit_bits": digit_bits}
     else:
         from oclradixsort_amd.dist import HipBackend, ShardedRadixSort

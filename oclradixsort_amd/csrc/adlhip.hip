@@ -666,7 +666,8 @@ int launch_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* s
 
 template <typename E, int K>
 int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* seg_start, size_t num_segments, int low_bits,
-                             const uint32_t* seg_cnt = nullptr, uint32_t in_stride = 0, const uint32_t* gate = nullptr)
+                             const uint32_t* seg_cnt = nullptr, uint32_t in_stride = 0, const uint32_t* gate = nullptr,
+                             const uint32_t* dyn_low_bits = nullptr)
 {
     constexpr int WAVES = 8;
     auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES>;
@@ -675,7 +676,7 @@ int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32
     const uint32_t grid = (uint32_t)((num_segments + WAVES - 1) / WAVES);
     return launch(d, sizeof(E) == 4 ? "segment_sort_wave_u32" : "segment_sort_wave_e64", [&] {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, d->stream, in, out, seg_start, (uint32_t)num_segments,
-                           (uint32_t)low_bits, d->d_fault, seg_cnt, in_stride, gate);
+                           (uint32_t)low_bits, d->d_fault, seg_cnt, in_stride, gate, dyn_low_bits);
     });
 }
 
@@ -846,6 +847,7 @@ int mid_sort_keys(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, s
     pa.src = data; pa.dst = slab; pa.cursors = state; pa.cursor_shift = 5; pa.src_count_shift = 0; pa.flag = state + 8192;
     pa.src_counts = nullptr; pa.n = (uint32_t)n; pa.src_stride = 0; pa.tiles_per_bucket = 1; pa.dst_stride = L.stride;
     pa.dst_total = 256u * L.stride; pa.start_bit = 24; pa.zero_me = state + 8194;
+    pa.sample = nullptr; pa.which_digit = 0;
     int rc = launch(d, "mid_bucket_scatter_u32", [&] {
         hipLaunchKernelGGL(ka, dim3(tiles), dim3(256), CA::LDS_BYTES, d->stream, pa);
     });
@@ -859,8 +861,9 @@ int mid_sort_keys(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, s
 }
 
 // ---- large keys-only sort: two unstable MSD passes with bucket cursors + LDS finish (hybrid_kernels.hpp "sort.msd2") ------
-constexpr size_t kMsd2Min = size_t(4) << 20;                       // keys; the path works from here ("sort.msd2" = 2) ...
-constexpr size_t kMsd2AutoMin = size_t(6) << 20;                   // ... and is chosen from here (profiles/r2_msd2_size_curve.txt)
+constexpr size_t kMsd2Min = size_t(1) << 20;                       // keys; the path works from here ("sort.msd2" = 2) ...
+constexpr size_t kMsd2AutoMin = size_t(2) << 20;                   // ... and is chosen above the mid-size sort's range
+                                                                   // (profiles/r2_msd2_size_curve.txt: 2.5 Mi keys 58 vs 70 us)
 constexpr size_t kMsd2Max = (size_t(1) << 26) + (size_t(1) << 20); // mean segment n / 65536 <= ~1040 of a 1280-key LDS tile
 constexpr uint32_t kMsd2StrideB = 1280;                            // = 64 * 20: the wave kernel's tile
 
@@ -919,11 +922,13 @@ int msd2_sort(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, size_
     if (!d->d_msd2) {   // first use on this handle: cursors of both passes + flag + done counter, zero between sorts
         HIPCHK(hipMalloc(&d->d_msd2, (8192 + 65536 + 64) * 4));
         HIPCHK(hipMemsetAsync(d->d_msd2, 0, (8192 + 65536 + 64) * 4, d->stream));
+        HIPCHK(hipMemsetAsync(d->d_msd2 + 8192 + 65536 + 10, 0xff, 8, d->stream));   // the sample's AND words
     }
     uint32_t* cur_a = d->d_msd2;            // 256 cursors, one 128-byte line each
     uint32_t* cur_b = d->d_msd2 + 8192;     // 65536 cursors, packed (16 atomics each per sort)
     uint32_t* flag = d->d_msd2 + 8192 + 65536;
     uint32_t* done = flag + 1;
+    uint32_t* sample = flag + 8;            // or lo, or hi, and lo, and hi (hybrid_kernels.hpp msd2_placement)
     const Msd2Layout L = msd2_layout(d, n);
     char* wb = reinterpret_cast<char*>(work);
     uint32_t* mode = reinterpret_cast<uint32_t*>(wb + L.off_mode);
@@ -934,19 +939,26 @@ int msd2_sort(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, size_
     using CT = adlhip::TileCfg<E, 8, 512, 32>;
     auto kern = adlhip::msd_bucket_scatter_kernel<E, 512, 32>;
     if (ensure_lds(kern, CT::LDS_BYTES)) return ADLHIP_FAILURE;
-    adlhip::BucketPass<E> pa;   // pass 1: the input, top byte -> 256 bucket slabs
+    // where the two digits sit is chosen on the device from a sample of the keys (hybrid_kernels.hpp msd2_sample_kernel)
+    int rc = launch(d, "msd2_sample", [&] {
+        hipLaunchKernelGGL(adlhip::msd2_sample_kernel<E>, dim3(adlhip::kSampleWGs), dim3(64), 0, d->stream, (const E*)data, (uint32_t)n,
+                           sample);
+    });
+    if (rc) return rc;
+    adlhip::BucketPass<E> pa;   // pass 1: the input, first digit -> 256 bucket slabs
     pa.src = data; pa.dst = slab_a; pa.cursors = cur_a; pa.cursor_shift = 5; pa.src_count_shift = 0; pa.flag = flag;
     pa.src_counts = nullptr; pa.n = (uint32_t)n;
     pa.src_stride = 0; pa.tiles_per_bucket = 1; pa.dst_stride = L.stride_a; pa.dst_total = 256u * L.stride_a; pa.start_bit = 24;
-    pa.zero_me = nullptr;
+    pa.zero_me = nullptr; pa.sample = sample; pa.which_digit = 1;
     const uint32_t tiles_a = (uint32_t)((n + CT::TILE - 1) / CT::TILE);
-    int rc = launch(d, "msd2_pass1_u32", [&] { hipLaunchKernelGGL(kern, dim3(tiles_a), dim3(512), CT::LDS_BYTES, d->stream, pa); });
+    rc = launch(d, "msd2_pass1_u32", [&] { hipLaunchKernelGGL(kern, dim3(tiles_a), dim3(512), CT::LDS_BYTES, d->stream, pa); });
     if (rc) return rc;
     adlhip::BucketPass<E> pb;   // pass 2: every bucket, second byte -> 65536 segment slabs
     pb.src = slab_a; pb.dst = slab_b; pb.cursors = cur_b; pb.cursor_shift = 0; pb.src_count_shift = 5; pb.flag = flag;
     pb.src_counts = cur_a; pb.n = (uint32_t)n;
     pb.src_stride = L.stride_a; pb.tiles_per_bucket = L.tiles_per_bucket; pb.dst_stride = kMsd2StrideB;
     pb.dst_total = 65536u * kMsd2StrideB; pb.start_bit = 16; pb.zero_me = nullptr;
+    pb.sample = sample; pb.which_digit = 2;
     rc = launch(d, "msd2_pass2_u32", [&] {
         hipLaunchKernelGGL(kern, dim3(256 * L.tiles_per_bucket), dim3(512), CT::LDS_BYTES, d->stream, pb);
     });
@@ -954,10 +966,10 @@ int msd2_sort(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, size_
     uint32_t* bar = done + 1;
     rc = launch(d, "msd2_offsets", [&] {
         hipLaunchKernelGGL(adlhip::msd2_offsets_kernel, dim3(256), dim3(256), 0, d->stream, cur_a, cur_b, flag, done, bar, seg_cnt, seg_off,
-                           mode, d->h_fault + 11, (uint32_t)n);
+                           mode, d->h_fault + 11, (uint32_t)n, sample);
     });
     if (rc) return rc;
-    rc = launch_wave_segment_sort<E, 20>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, kMsd2StrideB, mode);
+    rc = launch_wave_segment_sort<E, 20>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, kMsd2StrideB, mode, mode + adlhip::kDynLowBits);
     if (rc) return rc;
     // the safety net: ONE launch that returns at its first instruction unless the mode word is set, in which case its 256
     // resident workgroups sort the untouched input with the cooperative LSD sort (hybrid_kernels.hpp coop_lsd_sort)

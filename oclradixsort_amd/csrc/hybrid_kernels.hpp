@@ -384,39 +384,20 @@ __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, c
 // ------------------------------------------------------------------------------------------
 // Slab form (seg_cnt != nullptr; the large keys-only sort): segment s is in[s * in_stride, + seg_cnt[s]) and goes to
 // out[seg_start[s] ...); the kernel returns at once when *gate is non-zero.
-template <typename E, int K, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* in, E* out, const uint32_t* __restrict__ seg_start,
-                                                                        uint32_t num_segments, uint32_t low_bits, uint32_t* fault,
-                                                                        const uint32_t* __restrict__ seg_cnt, uint32_t in_stride,
-                                                                        const uint32_t* __restrict__ gate)
+// The body for segments of R-1 or R rows of 64 elements, R a compile-time constant: rows 0 .. R-3 are full and carry no
+// predicate, only the last two are tested per lane.  (With one body for all sizes and `if (row < rows && lane has an item)`
+// around every item the kernel spent ~1200 wave instructions per segment.  Filling up with all-ones pads instead of testing
+// is worse: up to 127 pads bump ONE counter, and same-address LDS atomics serialise.)
+template <typename E, int R>
+__device__ __forceinline__ void wave_sort_rows(const E* __restrict__ src, E* __restrict__ dst, uint32_t m, int lane,
+                                               E* __restrict__ buf, uint32_t* __restrict__ cnt, uint32_t low_bits)
 {
-    if (gate && *gate != 0u) return;
-    constexpr int CAP = 64 * K;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = (int)threadIdx.x & 63;
-    const int w = (int)threadIdx.x >> 6;
-    unsigned char* mine = smem + (size_t)w * (sizeof(E) * CAP + 256 * 4);
-    E* __restrict__ buf = reinterpret_cast<E*>(mine);
-    uint32_t* __restrict__ cnt = reinterpret_cast<uint32_t*>(mine + sizeof(E) * CAP);
-
-    const uint32_t seg = blockIdx.x * (uint32_t)WAVES + (uint32_t)w;
-    if (seg >= num_segments) return;
-    const uint32_t begin = seg_start[seg];
-    const uint32_t m = seg_cnt ? seg_cnt[seg] : seg_start[seg + 1] - begin;
-    if (m == 0u) return;
-    if (m > (uint32_t)CAP || low_bits > 16u) {   // never sort wrongly in silence
-        if (lane == 0) atomicOr(fault + 1, 0x40000u);
-        return;
-    }
-    const E* src = in + (seg_cnt ? (size_t)seg * in_stride : (size_t)begin);
-    E* dst = out + begin;
-    const int keff = (int)((m + 63u) >> 6);
     const int rem = (int)m - lane;   // item j of this lane exists iff j*64 < rem
-    E e[K];
+    constexpr int F = R > 2 ? R - 2 : 0;   // rows that are certainly full
+    E e[R];
 #pragma unroll
-    for (int j = 0; j < K; ++j)
-        if (j < keff) e[j] = (j * 64 < rem) ? src[j * 64 + lane] : E(0);
-
+    for (int j = 0; j < R; ++j)
+        if (j < F || j * 64 < rem) e[j] = src[j * 64 + lane];
     const int npass = low_bits > 8u ? 2 : 1;
     int sb = 0;
     for (int p = 0; p < npass; ++p) {
@@ -426,8 +407,8 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
         const u32x4 z = {0u, 0u, 0u, 0u};
         *reinterpret_cast<u32x4*>(cnt + 4 * lane) = z;
 #pragma unroll
-        for (int j = 0; j < K; ++j)
-            if (j < keff && j * 64 < rem) __hip_atomic_fetch_add(&cnt[digit(e[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        for (int j = 0; j < R; ++j)
+            if (j < F || j * 64 < rem) __hip_atomic_fetch_add(&cnt[digit(e[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         {   // counts -> bin starts
             const u32x4 c = *reinterpret_cast<const u32x4*>(cnt + 4 * lane);
             const uint32_t s4 = c.x + c.y + c.z + c.w;
@@ -440,21 +421,64 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
             *reinterpret_cast<u32x4*>(cnt + 4 * lane) = o;
         }
 #pragma unroll
-        for (int j = 0; j < K; ++j)
-            if (j < keff && j * 64 < rem) {
+        for (int j = 0; j < R; ++j)
+            if (j < F || j * 64 < rem) {
                 const uint32_t pos = __hip_atomic_fetch_add(&cnt[digit(e[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 buf[pos] = e[j];
             }
         if (p + 1 < npass) {
 #pragma unroll
-            for (int j = 0; j < K; ++j)
-                if (j < keff && j * 64 < rem) e[j] = buf[j * 64 + lane];
+            for (int j = 0; j < R; ++j)
+                if (j < F || j * 64 < rem) e[j] = buf[j * 64 + lane];
         }
         sb += nb;
     }
 #pragma unroll
-    for (int j = 0; j < K; ++j)
-        if (j < keff && j * 64 < rem) dst[j * 64 + lane] = buf[j * 64 + lane];
+    for (int j = 0; j < R; ++j)
+        if (j < F || j * 64 < rem) dst[j * 64 + lane] = buf[j * 64 + lane];
+}
+
+// rows -> the smallest body that holds them (bodies for 2, 4, ..., K rows)
+template <typename E, int R, int K>
+__device__ __forceinline__ void wave_sort_dispatch(int rows, const E* __restrict__ src, E* __restrict__ dst, uint32_t m, int lane,
+                                                   E* __restrict__ buf, uint32_t* __restrict__ cnt, uint32_t low_bits)
+{
+    if constexpr (R >= K) {
+        wave_sort_rows<E, K>(src, dst, m, lane, buf, cnt, low_bits);
+    } else {
+        if (rows <= R) wave_sort_rows<E, R>(src, dst, m, lane, buf, cnt, low_bits);
+        else wave_sort_dispatch<E, R + 2, K>(rows, src, dst, m, lane, buf, cnt, low_bits);
+    }
+}
+
+template <typename E, int K, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* in, E* out, const uint32_t* __restrict__ seg_start,
+                                                                        uint32_t num_segments, uint32_t low_bits, uint32_t* fault,
+                                                                        const uint32_t* __restrict__ seg_cnt, uint32_t in_stride,
+                                                                        const uint32_t* __restrict__ gate,
+                                                                        const uint32_t* __restrict__ dyn_low_bits)
+{
+    if (gate && *gate != 0u) return;
+    if (dyn_low_bits) low_bits = *dyn_low_bits;
+    constexpr int CAP = 64 * K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = (int)threadIdx.x & 63;
+    const int w = (int)threadIdx.x >> 6;
+    unsigned char* mine = smem + (size_t)w * (sizeof(E) * CAP + 256 * 4);
+    E* __restrict__ buf = reinterpret_cast<E*>(mine);
+    uint32_t* __restrict__ cnt = reinterpret_cast<uint32_t*>(mine + sizeof(E) * CAP);
+    // wave-uniform values, said so (derived from threadIdx they count as divergent)
+    const uint32_t seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)WAVES + (uint32_t)w));
+    if (seg >= num_segments) return;
+    const uint32_t begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_start[seg]);
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seg_cnt ? seg_cnt[seg] : seg_start[seg + 1] - begin));
+    if (m == 0u) return;
+    if (m > (uint32_t)CAP || low_bits > 16u) {   // never sort wrongly in silence
+        if (lane == 0) atomicOr(fault + 1, 0x40000u);
+        return;
+    }
+    const E* src = in + (seg_cnt ? (size_t)seg * in_stride : (size_t)begin);
+    wave_sort_dispatch<E, 2, K>((int)((m + 63u) >> 6), src, out + begin, m, lane, buf, cnt, low_bits);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -487,7 +511,54 @@ struct BucketPass {
     uint32_t dst_total;           // elements of the whole destination array
     int start_bit;
     uint32_t* zero_me;            // one word the first workgroup clears (the safety net's barrier counter), or nullptr
+    const uint32_t* sample;       // nullptr, or the four sample words (msd2_placement): start_bit = top - 8 * which_digit
+    int which_digit;              // 1 = first digit, 2 = second
 };
+
+// Digit placement of the large keys-only sort, chosen on the device from a sample of the keys: keys that do not use their top
+// bits -- the local sort of a multi-GPU sort sees 1/8 of the key range, indices stay below 2^28 -- would put everything into a
+// few buckets if the first digit were always the top byte.  msd2_sample_kernel ORs and ANDs 1024 keys into four words that
+// belong to the device handle (or = 0 / and = ~0 between sorts; the offsets kernel resets them); every consumer derives
+//   top = one past the highest bit in which two sampled keys differ (at least 16)
+// first digit = bits [top-8, top), second = [top-16, top-8), the LDS finish sorts the top-16 bits below.  The bits from `top`
+// up are the same in every sampled key; the first pass checks that for EVERY key and sends the sort to its safety net
+// otherwise (a sample can miss an outlier).
+struct Msd2Placement {
+    int top;
+    unsigned long long prefix;   // key >> top of every key (top < key bits)
+};
+__device__ __forceinline__ Msd2Placement msd2_placement(const uint32_t* __restrict__ sample /* or lo, or hi, and lo, and hi */)
+{
+    const unsigned long long o = ((unsigned long long)sample[1] << 32) | sample[0];
+    const unsigned long long a = ((unsigned long long)sample[3] << 32) | sample[2];
+    const unsigned long long diff = o ^ a;
+    Msd2Placement p;
+    p.top = diff ? 64 - __builtin_clzll(diff) : 0;
+    if (p.top < 16) p.top = 16;
+    p.prefix = p.top < 64 ? (o >> p.top) : 0ull;
+    return p;
+}
+constexpr int kSampleWGs = 16;
+enum { kDynMode = 0, kDynLowBits = 4 };   // words of the sort's mode block (work buffer): [4] = bits the finish sorts
+
+template <typename E>
+__global__ __launch_bounds__(64) void msd2_sample_kernel(const E* __restrict__ src, uint32_t n, uint32_t* sample)
+{
+    const unsigned long long k = (unsigned long long)(blockIdx.x * 64u + threadIdx.x);
+    const unsigned long long v = (unsigned long long)src[(size_t)(k * (unsigned long long)n / (unsigned long long)(kSampleWGs * 64))];
+    unsigned long long o = v, a = v;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        o |= __shfl_xor(o, sh);
+        a &= __shfl_xor(a, sh);
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_or(sample + 0, (uint32_t)o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_or(sample + 1, (uint32_t)(o >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_and(sample + 2, (uint32_t)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_and(sample + 3, (uint32_t)(a >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // The tile body is the one-sweep pass's (onesweep_kernels.hpp onesweep_chain_kernel) without its ticket, status rows and
 // look-back: load (wave-striped) -> rank (returning DS atomics) | barrier | every wave folds the counts and writes its own
@@ -523,7 +594,12 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
-    const int start_bit = a.start_bit;
+    int start_bit = a.start_bit;
+    Msd2Placement place{0, 0ull};
+    if (a.sample) {
+        place = msd2_placement(a.sample);
+        start_bit = place.top - 8 * a.which_digit;
+    }
     uint32_t* my_wcnt = s_wcnt + w * BINS;
     const IO io{a.src, a.dst};
     const bool scaled = dst_fits32<IO>(a.dst_total);
@@ -541,6 +617,16 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
 #pragma unroll
             for (int j = 0; j < K; ++j) e[j] = (j * 64 < rem) ? p.at(j * 64) : ~E(0);
         }
+    }
+    if (a.sample && a.which_digit == 1 && place.top < (int)(8 * sizeof(E))) {
+        // a key outside the sampled range would land in a wrong bucket: let the safety net sort instead
+        const E pre = (E)place.prefix;
+        const int rem = (int)valid - (int)wbase;
+        E bad = E(0);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j * 64 < rem) bad |= (e[j] >> place.top) ^ pre;
+        if (bad != E(0)) __hip_atomic_fetch_or(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- rank ---------------------------------------------------------------------------------------------------------
 #pragma unroll
@@ -637,7 +723,8 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, uint32_t* cursors_b, uint32_t* flag, uint32_t* done,
                                                            uint32_t* bar, uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_off,
-                                                           uint32_t* __restrict__ mode, uint32_t* host_mode, uint32_t n)
+                                                           uint32_t* __restrict__ mode, uint32_t* host_mode, uint32_t n,
+                                                           uint32_t* sample)
 {
     __shared__ uint32_t s_wsum[256 / 64 + 1];
     __shared__ uint32_t s_misc[4];
@@ -661,6 +748,13 @@ __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, 
             const uint32_t f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *mode = f ? 1u : 0u;
             seg_off[65536] = n;
+            if (sample) {   // the finish sorts the bits below the second digit; the sample words go back to or = 0 / and = ~0
+                mode[kDynLowBits] = (uint32_t)(msd2_placement(sample).top - 16);
+                __hip_atomic_store(sample + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sample + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sample + 2, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sample + 3, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // grid-barrier counter of the safety net

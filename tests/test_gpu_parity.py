@@ -1121,7 +1121,21 @@ def test_large_keys_only_sort_two_msd_passes_and_lds_finish(dev):
         }
         for nm, k in skewed.items():
             assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), nm
-        k = oracle.keys_u32(1 << 26, seed=3) >> np.uint32(8)   # the safety net at the top of the range
+        # keys that leave their top bits unused: the digits are placed below them (a sample of the keys decides where)
+        narrow = {
+            "one eighth of the key range (a rank of an 8-GPU sort)": (u >> np.uint32(3)) | np.uint32(0xa0000000),
+            "below 2^28": u >> np.uint32(4),
+            "below 2^20": u >> np.uint32(12),
+            "range that is not a power of two": (u % np.uint32(3 << 27)) + np.uint32(1 << 30),
+        }
+        for nm, k in narrow.items():
+            assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), nm
+        # ... and a sample can miss outliers: the first pass checks every key and hands over to the safety net
+        k = (u >> np.uint32(8)).copy()
+        k[12345] = 0xf0000001
+        k[n - 2] = 0x80000000
+        assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), "outliers above the sampled range"
+        k = oracle.keys_u32(1 << 26, seed=3) >> np.uint32(8)   # the top of the size range, digits placed at bits 8..23
         assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), "below 2^24 at 64Mi"
         DeviceUtils.waitForCompletion(dev)
         # and the automatic choice (hints included) stays correct when friendly and skewed inputs alternate
