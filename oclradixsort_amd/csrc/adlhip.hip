@@ -669,9 +669,13 @@ int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32
                              const uint32_t* seg_cnt = nullptr, uint32_t in_stride = 0, const uint32_t* gate = nullptr,
                              const uint32_t* dyn_low_bits = nullptr)
 {
-    constexpr int WAVES = 8;
-    auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES>;
-    const size_t lds = (size_t)WAVES * (sizeof(E) * 64 * K + 256 * 4);
+    // a wave's LDS: its tile + 256 counters; waves per workgroup so that a workgroup takes at most ~48 KiB (three per CU)
+    constexpr size_t per_wave = sizeof(E) * 64 * K + 256 * 4;
+    constexpr int WAVES = per_wave <= 6144 ? 8 : per_wave <= 12288 ? 4 : per_wave <= 24576 ? 2 : 1;
+    constexpr int STEP = K <= 40 ? 2 : 4;        // row-count bodies: every 2 rows, every 4 for the largest tile
+    constexpr int RMIN = K <= 20 ? 2 : K / 2;    // the tiles beyond 20 rows exist for segments that need them
+    auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES, STEP, RMIN>;
+    const size_t lds = (size_t)WAVES * per_wave;
     if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
     const uint32_t grid = (uint32_t)((num_segments + WAVES - 1) / WAVES);
     return launch(d, sizeof(E) == 4 ? "segment_sort_wave_u32" : "segment_sort_wave_e64", [&] {
@@ -861,38 +865,55 @@ int mid_sort_keys(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, s
 }
 
 // ---- large keys-only sort: two unstable MSD passes with bucket cursors + LDS finish (hybrid_kernels.hpp "sort.msd2") ------
+// u32 keys and u64 keys (equal keys are indistinguishable, so the passes need not be stable); pairs keep the stable paths.
 constexpr size_t kMsd2Min = size_t(1) << 20;                       // keys; the path works from here ("sort.msd2" = 2) ...
 constexpr size_t kMsd2AutoMin = size_t(2) << 20;                   // ... and is chosen above the mid-size sort's range
                                                                    // (profiles/r2_msd2_size_curve.txt: 2.5 Mi keys 58 vs 70 us)
-constexpr size_t kMsd2Max = (size_t(1) << 26) + (size_t(1) << 20); // mean segment n / 65536 <= ~1040 of a 1280-key LDS tile
-constexpr uint32_t kMsd2StrideB = 1280;                            // = 64 * 20: the wave kernel's tile
+constexpr size_t kMsd2MaxU32 = size_t(280) << 20;                  // mean segment n / 65536 = 4480, + 7.5 sd <= 5120
+constexpr size_t kMsd2MaxU64 = (size_t(1) << 28) + (size_t(1) << 22);   // mean segment 4160
+// the wave-per-segment finish's tiles: 64 * 20, 64 * 40, 64 * 80 elements
 
 struct Msd2Layout {
     size_t off_mode, off_cnt, off_off, off_coop, off_slab_a, off_slab_b, total;
-    uint32_t stride_a, tiles_per_bucket;
+    uint32_t stride_a, stride_b, tiles_per_bucket;
 };
 
-Msd2Layout msd2_layout(const adlhip_device* d, size_t n)
+// slab of a segment = the smallest of the finish's tiles that holds its mean + 7.5 standard deviations of a uniform key
+// distribution (64 Mi keys: 1024 + 240 of 1280; a segment beyond its slab sends the sort to the safety net, it is never
+// wrong; at 7.5 sd that is one sort in 10^8)
+uint32_t msd2_stride_b(size_t n)
+{
+    const size_t mean = (n + 65535) / 65536;
+    size_t sd = 1;
+    while (sd * sd < mean) ++sd;
+    const size_t need = mean + (15 * sd + 1) / 2;
+    return need <= 1280 ? 1280u : need <= 2560 ? 2560u : 5120u;
+}
+
+Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
 {
     Msd2Layout L;
-    const size_t base = 0;
-    (void)d;
+    const uint32_t tile = elem_bytes == 4 ? 16384u : 8192u;   // TileCfg<E, 8, 512, 32 | 16>
     L.stride_a = (uint32_t)align_up(n / 256 + n / 8192 + 4096, 64);   // mean bucket + 3 % + 4096
-    L.tiles_per_bucket = (L.stride_a + 16383) / 16384;
-    L.off_mode = base;
+    L.stride_b = msd2_stride_b(n);
+    L.tiles_per_bucket = (L.stride_a + tile - 1) / tile;
+    L.off_mode = 0;
     L.off_cnt = L.off_mode + 256;
     L.off_off = L.off_cnt + 65536 * 4;
     L.off_coop = align_up(L.off_off + 65537 * 4, 256);                       // safety net: table [256][256] + 256 totals
     L.off_slab_a = align_up(L.off_coop + (size_t)256 * 256 * 4 + 1024, 256);
-    L.off_slab_b = align_up(L.off_slab_a + (size_t)256 * L.stride_a * 4, 256);
-    L.total = L.off_slab_b + (size_t)65536 * kMsd2StrideB * 4;
+    L.off_slab_b = align_up(L.off_slab_a + (size_t)256 * L.stride_a * elem_bytes, 256);
+    L.total = L.off_slab_b + (size_t)65536 * L.stride_b * elem_bytes;
     return L;
 }
 
-bool msd2_eligible(const adlhip_device* d, size_t n, int sort_bits)
+// elem_bytes 4: u32 keys, sort_bits 32; elem_bytes 8 with max_bits 64: u64 keys, sort_bits 64
+bool msd2_eligible(const adlhip_device* d, size_t elem_bytes, size_t n, int sort_bits, int max_bits)
 {
-    return d->sort_algo < 0 && d->msd2_path && sort_bits == 32 && d->rank_mode == 1 && d->digit_bits == 8 && d->tile_variant < 0 &&
-           n > (d->msd2_path == 2 ? kMsd2Min : kMsd2AutoMin) && n <= kMsd2Max;
+    if (!(d->sort_algo < 0 && d->msd2_path && d->rank_mode == 1 && d->digit_bits == 8 && d->tile_variant < 0)) return false;
+    if (sort_bits != max_bits || (int)elem_bytes * 8 != max_bits) return false;   // whole keys only; {key, value} pairs: never
+    if (n <= (d->msd2_path == 2 ? kMsd2Min : kMsd2AutoMin)) return false;
+    return n <= (elem_bytes == 4 ? kMsd2MaxU32 : kMsd2MaxU64);
 }
 
 // Host-side hint, as for the mid-size sort: after a sort whose keys did not fit the slabs (reported into pinned memory by
@@ -916,9 +937,12 @@ bool msd2_wanted(adlhip_device* d)
     return true;
 }
 
-int msd2_sort(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, size_t n)
+template <typename E>
+int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
 {
-    typedef uint32_t E;
+    constexpr int K = sizeof(E) == 4 ? 32 : 16;
+    constexpr int KEY_BITS = 8 * (int)sizeof(E);
+    constexpr bool k32 = sizeof(E) == 4;   // profile names are kept by pointer: literals only
     if (!d->d_msd2) {   // first use on this handle: cursors of both passes + flag + done counter, zero between sorts
         HIPCHK(hipMalloc(&d->d_msd2, (8192 + 65536 + 64) * 4));
         HIPCHK(hipMemsetAsync(d->d_msd2, 0, (8192 + 65536 + 64) * 4, d->stream));
@@ -929,15 +953,15 @@ int msd2_sort(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, size_
     uint32_t* flag = d->d_msd2 + 8192 + 65536;
     uint32_t* done = flag + 1;
     uint32_t* sample = flag + 8;            // or lo, or hi, and lo, and hi (hybrid_kernels.hpp msd2_placement)
-    const Msd2Layout L = msd2_layout(d, n);
+    const Msd2Layout L = msd2_layout(n, sizeof(E));
     char* wb = reinterpret_cast<char*>(work);
     uint32_t* mode = reinterpret_cast<uint32_t*>(wb + L.off_mode);
     uint32_t* seg_cnt = reinterpret_cast<uint32_t*>(wb + L.off_cnt);
     uint32_t* seg_off = reinterpret_cast<uint32_t*>(wb + L.off_off);
     E* slab_a = reinterpret_cast<E*>(wb + L.off_slab_a);
     E* slab_b = reinterpret_cast<E*>(wb + L.off_slab_b);
-    using CT = adlhip::TileCfg<E, 8, 512, 32>;
-    auto kern = adlhip::msd_bucket_scatter_kernel<E, 512, 32>;
+    using CT = adlhip::TileCfg<E, 8, 512, K>;
+    auto kern = adlhip::msd_bucket_scatter_kernel<E, 512, K>;
     if (ensure_lds(kern, CT::LDS_BYTES)) return ADLHIP_FAILURE;
     // where the two digits sit is chosen on the device from a sample of the keys (hybrid_kernels.hpp msd2_sample_kernel)
     int rc = launch(d, "msd2_sample", [&] {
@@ -948,18 +972,18 @@ int msd2_sort(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, size_
     adlhip::BucketPass<E> pa;   // pass 1: the input, first digit -> 256 bucket slabs
     pa.src = data; pa.dst = slab_a; pa.cursors = cur_a; pa.cursor_shift = 5; pa.src_count_shift = 0; pa.flag = flag;
     pa.src_counts = nullptr; pa.n = (uint32_t)n;
-    pa.src_stride = 0; pa.tiles_per_bucket = 1; pa.dst_stride = L.stride_a; pa.dst_total = 256u * L.stride_a; pa.start_bit = 24;
+    pa.src_stride = 0; pa.tiles_per_bucket = 1; pa.dst_stride = L.stride_a; pa.dst_total = 256u * L.stride_a; pa.start_bit = KEY_BITS - 8;
     pa.zero_me = nullptr; pa.sample = sample; pa.which_digit = 1;
     const uint32_t tiles_a = (uint32_t)((n + CT::TILE - 1) / CT::TILE);
-    rc = launch(d, "msd2_pass1_u32", [&] { hipLaunchKernelGGL(kern, dim3(tiles_a), dim3(512), CT::LDS_BYTES, d->stream, pa); });
+    rc = launch(d, k32 ? "msd2_pass1_u32" : "msd2_pass1_u64", [&] { hipLaunchKernelGGL(kern, dim3(tiles_a), dim3(512), CT::LDS_BYTES, d->stream, pa); });
     if (rc) return rc;
-    adlhip::BucketPass<E> pb;   // pass 2: every bucket, second byte -> 65536 segment slabs
+    adlhip::BucketPass<E> pb;   // pass 2: every bucket, second digit -> 65536 segment slabs
     pb.src = slab_a; pb.dst = slab_b; pb.cursors = cur_b; pb.cursor_shift = 0; pb.src_count_shift = 5; pb.flag = flag;
     pb.src_counts = cur_a; pb.n = (uint32_t)n;
-    pb.src_stride = L.stride_a; pb.tiles_per_bucket = L.tiles_per_bucket; pb.dst_stride = kMsd2StrideB;
-    pb.dst_total = 65536u * kMsd2StrideB; pb.start_bit = 16; pb.zero_me = nullptr;
+    pb.src_stride = L.stride_a; pb.tiles_per_bucket = L.tiles_per_bucket; pb.dst_stride = L.stride_b;
+    pb.dst_total = 65536u * L.stride_b; pb.start_bit = KEY_BITS - 16; pb.zero_me = nullptr;
     pb.sample = sample; pb.which_digit = 2;
-    rc = launch(d, "msd2_pass2_u32", [&] {
+    rc = launch(d, k32 ? "msd2_pass2_u32" : "msd2_pass2_u64", [&] {
         hipLaunchKernelGGL(kern, dim3(256 * L.tiles_per_bucket), dim3(512), CT::LDS_BYTES, d->stream, pb);
     });
     if (rc) return rc;
@@ -969,16 +993,20 @@ int msd2_sort(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, size_
                            mode, d->h_fault + 11, (uint32_t)n, sample);
     });
     if (rc) return rc;
-    rc = launch_wave_segment_sort<E, 20>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, kMsd2StrideB, mode, mode + adlhip::kDynLowBits);
+    // the finish sorts the bits below the second digit (the offsets kernel has published how many), a wave per segment
+    const uint32_t* lowb = mode + adlhip::kDynLowBits;
+    if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
+    else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
+    else rc = launch_wave_segment_sort<E, 80>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
     if (rc) return rc;
     // the safety net: ONE launch that returns at its first instruction unless the mode word is set, in which case its 256
     // resident workgroups sort the untouched input with the cooperative LSD sort (hybrid_kernels.hpp coop_lsd_sort)
-    auto coop = adlhip::coop_lsd_sort_kernel<E, 512, 32>;
+    auto coop = adlhip::coop_lsd_sort_kernel<E, 512, K>;
     if (ensure_lds(coop, CT::LDS_BYTES)) return ADLHIP_FAILURE;
     uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
-    return launch(d, "msd2_coop_lsd_u32", [&] {
+    return launch(d, k32 ? "msd2_coop_lsd_u32" : "msd2_coop_lsd_u64", [&] {
         hipLaunchKernelGGL(coop, dim3(256), dim3(512), CT::LDS_BYTES, d->stream, data, tmp, (uint32_t)n, ctable, ctable + 256 * 256, bar,
-                           (const uint32_t*)mode, d->d_fault);
+                           (const uint32_t*)mode, d->d_fault, KEY_BITS);
     });
 }
 
@@ -991,7 +1019,8 @@ size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)
     else b = onesweep_layout(d, n, max_passes_for(d, 64), buf_tile<AosBuf<uint64_t>>(d, n)).total;   // as onesweep_sort<Buf>()
     const size_t c = n <= kMidMaxU32 ? mid_layout(n).total : mid_layout(kMidMaxU32).total;   // mid-size sort (monotone in n)
     size_t e = 0;   // large keys-only sort: slabs behind the one-sweep layout (monotone in n up to its limit)
-    if (elem_kind == ADLHIP_ELEM_U32 && n > kMsd2Min) e = msd2_layout(d, std::min(n, kMsd2Max)).total;
+    if (elem_kind == ADLHIP_ELEM_U32 && n > kMsd2Min) e = msd2_layout(std::min(n, kMsd2MaxU32), 4).total;
+    if (elem_kind == ADLHIP_ELEM_U64 && n > kMsd2Min) e = msd2_layout(std::min(n, kMsd2MaxU64), 8).total;
     return std::max(std::max(a, b), std::max(c, e));
 }
 
@@ -1055,9 +1084,7 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
         }
         if (form == 3) return mid_sort<E>(d, data, tmp, work, n);         // three launches
     }
-    if constexpr (sizeof(E) == 4) {
-        if (msd2_eligible(d, n, sort_bits) && msd2_wanted(d)) return msd2_sort(d, data, tmp, work, n);
-    }
+    if (msd2_eligible(d, sizeof(E), n, sort_bits, max_bits) && msd2_wanted(d)) return msd2_sort<E>(d, data, tmp, work, n);
     return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, n, plan);
 }
 

@@ -65,7 +65,7 @@ struct MidCoop {          // what the safety net needs beside the two arrays (ta
 
 template <typename E, int NT, int K>
 __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table, uint32_t* __restrict__ totals,
-                                              uint32_t* bar, uint32_t* fault, unsigned char* smem)
+                                              uint32_t* bar, uint32_t* fault, unsigned char* smem, int key_bits = 32)
 {
     using C = TileCfg<E, 8, NT, K>;
     constexpr int NW = NT / 64;
@@ -84,12 +84,12 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
     uint32_t target = 0u;   // mid_prep_kernel leaves the barrier counter at zero (done[1])
     E* src = data;
     E* dst = tmp;
-    for (int sb = 0; sb < 32; sb += 8) {
+    for (int sb = 0; sb < key_bits; sb += 8) {   // 32: u32 keys and {key, value} pairs; 64: u64 keys (an even number of passes)
         // ---- count the digits of this workgroup's run of tiles --------------------------------------------------------
         for (int i = tid; i < NW * 256; i += NT) hist[i] = 0u;
         __syncthreads();
         for (uint32_t i = e0 + (uint32_t)tid; i < e1; i += (uint32_t)NT)
-            atomicAdd(&hist[w * 256 + (((uint32_t)src[i] >> sb) & 255u)], 1u);
+            atomicAdd(&hist[w * 256 + ((uint32_t)(src[i] >> sb) & 255u)], 1u);
         __syncthreads();
         if (tid < 256) {
             uint32_t c = 0u;
@@ -132,11 +132,11 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
 template <typename E, int NT, int K>
 __global__ __launch_bounds__(NT) void coop_lsd_sort_kernel(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table,
                                                            uint32_t* __restrict__ totals, uint32_t* bar,
-                                                           const uint32_t* __restrict__ gate, uint32_t* fault)
+                                                           const uint32_t* __restrict__ gate, uint32_t* fault, int key_bits)
 {
     if (*gate == 0u) return;   // the large keys-only sort fitted its slabs: nothing to do
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    coop_lsd_sort<E, NT, K>(data, tmp, n, table, totals, bar, fault, smem);
+    coop_lsd_sort<E, NT, K>(data, tmp, n, table, totals, bar, fault, smem, key_bits);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, c
         for (int p = 0; p < npass; ++p) {
             const int nb = ((int)low_bits - sb + (npass - p - 1)) / (npass - p);
             const uint32_t mask = (1u << nb) - 1u;
-            auto digit = [&](E x) -> uint32_t { return ((uint32_t)x >> sb) & mask; };
+            auto digit = [&](E x) -> uint32_t { return (uint32_t)(x >> sb) & mask; };   // u64 keys: bits beyond 31 too
 #pragma unroll
             for (int q = 0; q < BPL; ++q) my_wcnt[q * 64 + lane] = 0u;
             uint32_t rnk[K];
@@ -384,26 +384,25 @@ __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, c
 // ------------------------------------------------------------------------------------------
 // Slab form (seg_cnt != nullptr; the large keys-only sort): segment s is in[s * in_stride, + seg_cnt[s]) and goes to
 // out[seg_start[s] ...); the kernel returns at once when *gate is non-zero.
-// The body for segments of R-1 or R rows of 64 elements, R a compile-time constant: rows 0 .. R-3 are full and carry no
-// predicate, only the last two are tested per lane.  (With one body for all sizes and `if (row < rows && lane has an item)`
+// The body for segments of F+1 .. R rows of 64 elements, R and F compile-time constants: rows 0 .. F-1 are full and carry no
+// predicate, only the last R - F are tested per lane.  (With one body for all sizes and `if (row < rows && lane has an item)`
 // around every item the kernel spent ~1200 wave instructions per segment.  Filling up with all-ones pads instead of testing
 // is worse: up to 127 pads bump ONE counter, and same-address LDS atomics serialise.)
-template <typename E, int R>
+template <typename E, int R, int F>
 __device__ __forceinline__ void wave_sort_rows(const E* __restrict__ src, E* __restrict__ dst, uint32_t m, int lane,
                                                E* __restrict__ buf, uint32_t* __restrict__ cnt, uint32_t low_bits)
 {
     const int rem = (int)m - lane;   // item j of this lane exists iff j*64 < rem
-    constexpr int F = R > 2 ? R - 2 : 0;   // rows that are certainly full
     E e[R];
 #pragma unroll
     for (int j = 0; j < R; ++j)
         if (j < F || j * 64 < rem) e[j] = src[j * 64 + lane];
-    const int npass = low_bits > 8u ? 2 : 1;
+    const int npass = ((int)low_bits + 7) / 8;   // 8-bit digits at most, as even as possible (u64 keys: up to six passes)
     int sb = 0;
     for (int p = 0; p < npass; ++p) {
-        const int nb = p + 1 < npass ? ((int)low_bits + 1) / 2 : (int)low_bits - sb;
+        const int nb = ((int)low_bits - sb + (npass - p - 1)) / (npass - p);
         const uint32_t mask = (1u << nb) - 1u;
-        auto digit = [&](E x) -> uint32_t { return ((uint32_t)x >> sb) & mask; };
+        auto digit = [&](E x) -> uint32_t { return (uint32_t)(x >> sb) & mask; };
         const u32x4 z = {0u, 0u, 0u, 0u};
         *reinterpret_cast<u32x4*>(cnt + 4 * lane) = z;
 #pragma unroll
@@ -438,20 +437,24 @@ __device__ __forceinline__ void wave_sort_rows(const E* __restrict__ src, E* __r
         if (j < F || j * 64 < rem) dst[j * 64 + lane] = buf[j * 64 + lane];
 }
 
-// rows -> the smallest body that holds them (bodies for 2, 4, ..., K rows)
-template <typename E, int R, int K>
+// rows -> the smallest body that holds them: bodies for RMIN (any number of rows up to RMIN: every row tested), RMIN + STEP,
+// ..., K rows.  A kernel for large tiles (K = 40, 80: segments of the large sort beyond 64 Mi keys) starts at K / 2 -- its
+// segments are that large -- and steps by 4 to keep the code size in bounds.
+template <typename E, int R, int K, int STEP, bool FIRST>
 __device__ __forceinline__ void wave_sort_dispatch(int rows, const E* __restrict__ src, E* __restrict__ dst, uint32_t m, int lane,
                                                    E* __restrict__ buf, uint32_t* __restrict__ cnt, uint32_t low_bits)
 {
+    constexpr int RR = R < K ? R : K;
+    constexpr int F = FIRST ? 0 : RR - STEP;
     if constexpr (R >= K) {
-        wave_sort_rows<E, K>(src, dst, m, lane, buf, cnt, low_bits);
+        wave_sort_rows<E, RR, F>(src, dst, m, lane, buf, cnt, low_bits);
     } else {
-        if (rows <= R) wave_sort_rows<E, R>(src, dst, m, lane, buf, cnt, low_bits);
-        else wave_sort_dispatch<E, R + 2, K>(rows, src, dst, m, lane, buf, cnt, low_bits);
+        if (rows <= R) wave_sort_rows<E, RR, F>(src, dst, m, lane, buf, cnt, low_bits);
+        else wave_sort_dispatch<E, R + STEP, K, STEP, false>(rows, src, dst, m, lane, buf, cnt, low_bits);
     }
 }
 
-template <typename E, int K, int WAVES>
+template <typename E, int K, int WAVES, int STEP, int RMIN>
 __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* in, E* out, const uint32_t* __restrict__ seg_start,
                                                                         uint32_t num_segments, uint32_t low_bits, uint32_t* fault,
                                                                         const uint32_t* __restrict__ seg_cnt, uint32_t in_stride,
@@ -473,12 +476,12 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
     const uint32_t begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_start[seg]);
     const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seg_cnt ? seg_cnt[seg] : seg_start[seg + 1] - begin));
     if (m == 0u) return;
-    if (m > (uint32_t)CAP || low_bits > 16u) {   // never sort wrongly in silence
+    if (m > (uint32_t)CAP || low_bits > 8u * (uint32_t)sizeof(E)) {   // never sort wrongly in silence
         if (lane == 0) atomicOr(fault + 1, 0x40000u);
         return;
     }
     const E* src = in + (seg_cnt ? (size_t)seg * in_stride : (size_t)begin);
-    wave_sort_dispatch<E, 2, K>((int)((m + 63u) >> 6), src, out + begin, m, lane, buf, cnt, low_bits);
+    wave_sort_dispatch<E, RMIN, K, STEP, true>((int)((m + 63u) >> 6), src, out + begin, m, lane, buf, cnt, low_bits);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -81,8 +81,7 @@ __device__ __forceinline__ uint32_t digit_of(uint32_t e, int start_bit)
 template <int NBITS>
 __device__ __forceinline__ uint32_t digit_of(uint64_t e, int start_bit)
 {
-    const uint32_t w = (start_bit & 32) ? (uint32_t)(e >> 32) : (uint32_t)e;
-    return (w >> (start_bit & 31)) & ((1u << NBITS) - 1u);
+    return (uint32_t)(e >> start_bit) & ((1u << NBITS) - 1u);   // any position: a digit may straddle bit 32 (placed digits)
 }
 
 // 64-lane "match any": the mask of lanes whose digit equals this lane's.  One ballot per digit bit;

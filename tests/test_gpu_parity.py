@@ -480,7 +480,7 @@ def test_stopwatch_and_profiling(dev, pp):
     rows = open(csv_path).read().splitlines()
     assert rows[0] == '"kernel","launches","total_ms","avg_ms"' and len(rows) >= 3
     assert ms > 0
-    assert any(k.startswith(("onesweep_u32", "scatter_u32")) for k in prof), prof
+    assert any(k.startswith(("onesweep_u32", "scatter_u32", "msd2_pass1_u32")) for k in prof), prof   # whichever path n selects
     assert sum(v[1] for v in prof.values()) > 0
     b.release()
 
@@ -1146,3 +1146,49 @@ def test_large_keys_only_sort_two_msd_passes_and_lds_finish(dev):
     finally:
         dev.setParam("sort.msd2", 1)
         p.close()
+
+
+def test_large_keys_only_sort_u64_keys(dev):
+    """The same path for u64 keys (BASELINE config #5's element): digits placed anywhere in the 64 bits (straddling bit 32
+    too), up to six 8-bit passes in the LDS finish, a workgroup per segment where segments outgrow a wave's tile."""
+    dev.setParam("sort.msd2", 2)
+    p = Pprims()
+    try:
+        for n in ((1 << 20) + 77, 3000001, 1 << 24, (1 << 26) + 4321):
+            k = oracle.keys_u64(n, seed=n & 0xff)
+            assert np.array_equal(gpu_sort_u64(dev, p, k), oracle.sort_u64(k)), ("uniform", n)
+        n = (1 << 23) + 11
+        u = oracle.keys_u64(n, seed=5)
+        cases = {
+            "top 20 bits unused (digits straddle bit 32)": u >> np.uint64(20),
+            "top 28 bits unused": u >> np.uint64(28),
+            "values below 2^32": u >> np.uint64(32),
+            "values below 2^20": u >> np.uint64(44),
+            "constant high dword": (u & np.uint64(0xffffffff)) | np.uint64(0x1234567800000000),
+            "constant low dword": (u & np.uint64(0xffffffff00000000)) | np.uint64(0x9abcdef0),
+            "all equal": np.full(n, 0xdeadbeefcafef00d, dtype=np.uint64),
+            "sorted": np.sort(u),
+            "one heavy top byte": np.where(np.arange(n) % 10 != 0, u >> np.uint64(8), u).astype(np.uint64),
+        }
+        for nm, k in cases.items():
+            assert np.array_equal(gpu_sort_u64(dev, p, k), oracle.sort_u64(k)), nm
+        k = (u >> np.uint64(30)).copy()   # outliers above the sampled range
+        k[777] = 0xf000000000000001
+        k[n - 3] = 0x8000000000000000
+        assert np.array_equal(gpu_sort_u64(dev, p, k), oracle.sort_u64(k)), "outliers"
+        DeviceUtils.waitForCompletion(dev)
+    finally:
+        dev.setParam("sort.msd2", 1)
+        p.close()
+
+
+@pytest.mark.parametrize("n", [(1 << 27) + 5, 1 << 28], ids=["128Mi+5", "256Mi"])
+def test_large_keys_only_sort_beyond_64mi(dev, pp, n):
+    """u32 keys beyond 64 Mi (what a GPU of BASELINE config #4 sorts): segments outgrow the wave's tile, a workgroup finishes
+    each one.  Automatic choice; bit-exact against the oracle."""
+    keys = oracle.keys_u32(n, seed=n & 0xffff)
+    got = gpu_sort_u32(dev, pp, keys)
+    want = oracle.sort_u32(keys)
+    del keys
+    assert np.array_equal(got, want)
+    dev.checkFault()
