@@ -1010,6 +1010,125 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     });
 }
 
+// ---- the same for {key, value} pairs, STABLE: look-back instead of cursors (hybrid_kernels.hpp msd_lookback_scatter_kernel) --
+constexpr size_t kMsd2sAutoMin = size_t(2) << 20;   // pairs; above the mid-size sort's range
+constexpr size_t kMsd2sMax = (size_t(1) << 28) + (size_t(1) << 22);
+constexpr uint32_t kMsd2sTile = 8192;               // TileCfg<uint64_t, 8, 512, 16>
+
+struct Msd2sLayout {
+    size_t off_mode, off_place, off_cnt, off_off, off_coop, off_tickets, off_status_a, off_status_b, off_slab_a, off_slab_b, total;
+    uint32_t slice, rows_a, rows_b, stride_a, stride_b, ticket_words;
+    size_t status_bytes_a, status_bytes_b;
+};
+
+Msd2sLayout msd2s_layout(size_t n)
+{
+    Msd2sLayout L;
+    L.slice = (uint32_t)align_up((n + 15) / 16, kMsd2sTile);            // elements per chain of pass A
+    L.rows_a = L.slice / kMsd2sTile;
+    {   // sub-slab (digit, chain): mean slice / 256 + 8 standard deviations
+        const size_t mean = L.slice / 256;
+        size_t sd = 1;
+        while (sd * sd < mean) ++sd;
+        L.stride_a = (uint32_t)align_up(mean + 8 * sd + 64, 64);
+    }
+    L.rows_b = 16u * ((L.stride_a + kMsd2sTile - 1) / kMsd2sTile);     // the most tiles a bucket can have
+    L.stride_b = msd2_stride_b(n);
+    L.ticket_words = (16 + 256) * adlhip::kTicketStride;
+    L.status_bytes_a = (size_t)16 * L.rows_a * 1024;
+    L.status_bytes_b = (size_t)256 * L.rows_b * 1024;
+    L.off_mode = 0;
+    L.off_place = 128;
+    L.off_cnt = 256;
+    L.off_off = L.off_cnt + 65536 * 4;
+    L.off_coop = align_up(L.off_off + 65537 * 4, 256);
+    L.off_tickets = align_up(L.off_coop + (size_t)256 * 256 * 4 + 1024, 256);
+    L.off_status_a = align_up(L.off_tickets + (size_t)L.ticket_words * 4, 256);
+    L.off_status_b = L.off_status_a + L.status_bytes_a;
+    L.off_slab_a = align_up(L.off_status_b + L.status_bytes_b, 256);
+    L.off_slab_b = align_up(L.off_slab_a + (size_t)4096 * L.stride_a * 8, 256);
+    L.total = L.off_slab_b + (size_t)65536 * L.stride_b * 8;
+    return L;
+}
+
+bool msd2s_eligible(const adlhip_device* d, size_t elem_bytes, size_t n, int sort_bits, int max_bits)
+{
+    if (!(d->sort_algo < 0 && d->msd2_path && d->rank_mode == 1 && d->digit_bits == 8 && d->tile_variant < 0)) return false;
+    if (elem_bytes != 8 || max_bits != 32 || sort_bits != 32) return false;   // {key, value} pairs, whole keys
+    return n > (d->msd2_path == 2 ? kMsd2Min : kMsd2sAutoMin) && n <= kMsd2sMax;
+}
+
+int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size_t n)
+{
+    typedef uint64_t E;
+    if (!d->d_msd2) {
+        HIPCHK(hipMalloc(&d->d_msd2, (8192 + 65536 + 64) * 4));
+        HIPCHK(hipMemsetAsync(d->d_msd2, 0, (8192 + 65536 + 64) * 4, d->stream));
+        HIPCHK(hipMemsetAsync(d->d_msd2 + 8192 + 65536 + 10, 0xff, 8, d->stream));
+    }
+    uint32_t* flag = d->d_msd2 + 8192 + 65536;
+    uint32_t* done = flag + 1;
+    uint32_t* bar = flag + 2;
+    const Msd2sLayout L = msd2s_layout(n);
+    char* wb = reinterpret_cast<char*>(work);
+    uint32_t* mode = reinterpret_cast<uint32_t*>(wb + L.off_mode);
+    adlhip::StablePlace* place = reinterpret_cast<adlhip::StablePlace*>(wb + L.off_place);
+    uint32_t* seg_cnt = reinterpret_cast<uint32_t*>(wb + L.off_cnt);
+    uint32_t* seg_off = reinterpret_cast<uint32_t*>(wb + L.off_off);
+    uint32_t* tickets = reinterpret_cast<uint32_t*>(wb + L.off_tickets);
+    uint32_t* status_a = reinterpret_cast<uint32_t*>(wb + L.off_status_a);
+    uint32_t* status_b = reinterpret_cast<uint32_t*>(wb + L.off_status_b);
+    E* slab_a = reinterpret_cast<E*>(wb + L.off_slab_a);
+    E* slab_b = reinterpret_cast<E*>(wb + L.off_slab_b);
+    using CT = adlhip::TileCfg<E, 8, 512, 16>;
+    static_assert(CT::TILE == (int)kMsd2sTile, "layout and kernel agree on the tile");
+    auto kern = adlhip::msd_lookback_scatter_kernel<E, 512, 16>;
+    if (ensure_lds(kern, CT::LDS_BYTES)) return ADLHIP_FAILURE;
+    // status rows of both passes: zero (one memset; the rows are contiguous)
+    HIPCHK(hipMemsetAsync(status_a, 0, L.status_bytes_a + L.status_bytes_b, d->stream));
+    int rc = launch(d, "msd2s_prep", [&] {
+        hipLaunchKernelGGL(adlhip::msd2s_prep_kernel<E>, dim3(1), dim3(1024), 0, d->stream, (const E*)data, (uint32_t)n, place, tickets,
+                           L.ticket_words);
+    });
+    if (rc) return rc;
+    adlhip::LookbackPass<E> pa;
+    pa.src = data; pa.dst = slab_a; pa.status = status_a; pa.status_bytes = (uint32_t)L.status_bytes_a; pa.tickets = tickets;
+    pa.flag = flag; pa.fault = d->d_fault; pa.place = place; pa.which_digit = 1; pa.n = (uint32_t)n; pa.chains = 16;
+    pa.rows_per_chain = L.rows_a; pa.slice = L.slice; pa.src_stride = 0; pa.status_a = nullptr; pa.rows_per_chain_a = 0;
+    pa.dst_stride = L.stride_a; pa.dst_total = 4096u * L.stride_a;
+    rc = launch(d, "msd2s_pass1_kv32", [&] {
+        hipLaunchKernelGGL(kern, dim3(16 * L.rows_a), dim3(512), CT::LDS_BYTES, d->stream, pa);
+    });
+    if (rc) return rc;
+    adlhip::LookbackPass<E> pb = pa;
+    pb.src = slab_a; pb.dst = slab_b; pb.status = status_b; pb.status_bytes = (uint32_t)L.status_bytes_b;
+    pb.tickets = tickets + 16 * adlhip::kTicketStride; pb.which_digit = 2; pb.chains = 256; pb.rows_per_chain = L.rows_b;
+    pb.src_stride = L.stride_a; pb.status_a = status_a; pb.rows_per_chain_a = L.rows_a; pb.dst_stride = L.stride_b;
+    pb.dst_total = 65536u * L.stride_b;
+    rc = launch(d, "msd2s_pass2_kv32", [&] {
+        hipLaunchKernelGGL(kern, dim3(256 * L.rows_b), dim3(512), CT::LDS_BYTES, d->stream, pb);
+    });
+    if (rc) return rc;
+    rc = launch(d, "msd2s_offsets", [&] {
+        hipLaunchKernelGGL(adlhip::msd2s_offsets_kernel<CT::TILE>, dim3(256), dim3(256), 0, d->stream, (const uint32_t*)status_a, L.rows_a,
+                           L.slice, (const uint32_t*)status_b, L.rows_b, L.stride_a, flag, done, bar, seg_cnt, seg_off, mode,
+                           d->h_fault + 11, (uint32_t)n, (const adlhip::StablePlace*)place);
+    });
+    if (rc) return rc;
+    const uint32_t* lowb = mode + adlhip::kDynLowBits;
+    if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
+    else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
+    else rc = launch_wave_segment_sort<E, 80>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
+    if (rc) return rc;
+    auto coop = adlhip::coop_lsd_sort_kernel<E, 512, 16>;
+    if (ensure_lds(coop, CT::LDS_BYTES)) return ADLHIP_FAILURE;
+    uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
+    return launch(d, "msd2s_coop_lsd_kv32", [&] {
+        hipLaunchKernelGGL(coop, dim3(256), dim3(512), CT::LDS_BYTES, d->stream, data, tmp, (uint32_t)n, ctable, ctable + 256 * 256, bar,
+                           (const uint32_t*)mode, d->d_fault, 32);
+    });
+}
+
 size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)
 {
     const size_t a = work_bytes_three_kernel(d, n);
@@ -1021,6 +1140,7 @@ size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)
     size_t e = 0;   // large keys-only sort: slabs behind the one-sweep layout (monotone in n up to its limit)
     if (elem_kind == ADLHIP_ELEM_U32 && n > kMsd2Min) e = msd2_layout(std::min(n, kMsd2MaxU32), 4).total;
     if (elem_kind == ADLHIP_ELEM_U64 && n > kMsd2Min) e = msd2_layout(std::min(n, kMsd2MaxU64), 8).total;
+    if (elem_kind == ADLHIP_ELEM_KV32 && n > kMsd2Min) e = msd2s_layout(std::min(n, kMsd2sMax)).total;
     return std::max(std::max(a, b), std::max(c, e));
 }
 
@@ -1085,6 +1205,9 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
         if (form == 3) return mid_sort<E>(d, data, tmp, work, n);         // three launches
     }
     if (msd2_eligible(d, sizeof(E), n, sort_bits, max_bits) && msd2_wanted(d)) return msd2_sort<E>(d, data, tmp, work, n);
+    if constexpr (sizeof(E) == 8) {
+        if (msd2s_eligible(d, sizeof(E), n, sort_bits, max_bits) && msd2_wanted(d)) return msd2s_sort(d, data, tmp, work, n);
+    }
     return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, n, plan);
 }
 

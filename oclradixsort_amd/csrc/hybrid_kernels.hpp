@@ -398,6 +398,12 @@ __device__ __forceinline__ void wave_sort_rows(const E* __restrict__ src, E* __r
     for (int j = 0; j < R; ++j)
         if (j < F || j * 64 < rem) e[j] = src[j * 64 + lane];
     const int npass = ((int)low_bits + 7) / 8;   // 8-bit digits at most, as even as possible (u64 keys: up to six passes)
+    if (npass == 0) {   // nothing left to sort (the digits above covered every bit that varies): the segment only moves
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (j < F || j * 64 < rem) dst[j * 64 + lane] = e[j];
+        return;
+    }
     int sb = 0;
     for (int p = 0; p < npass; ++p) {
         const int nb = ((int)low_bits - sb + (npass - p - 1)) / (npass - p);
@@ -763,6 +769,329 @@ __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, 
             __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // grid-barrier counter of the safety net
             __hip_atomic_store(host_mode, 1u + (f ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The STABLE form of the large sort, for {key, value} pairs ("sort.msd2" as well): equal keys must keep their order, so a
+// tile cannot take whatever room an atomic cursor hands it.  Same two MSD passes into slabs and the same finish, but a tile
+// learns where its run of a digit goes by decoupled LOOK-BACK over the tiles before it in its chain (the one-sweep pass's
+// status rows and lookback_exclusive4, onesweep_kernels.hpp) -- and since every (digit, chain) pair has a slab of its own,
+// no histogram and no offset table is needed:
+//   pass A  16 chains = 16 equal slices of the input (in order); the run of digit d of a tile of chain c goes to sub-slab
+//           (d, c) = slab_a[(d * 16 + c) * stride_a ...) behind the runs of the chain's earlier tiles.  Bucket d = its 16
+//           sub-slabs in order: input order is kept.
+//   pass B  256 chains = the buckets; chain b's tiles walk its 16 sub-slabs in order (their sizes are the last status rows of
+//           pass A's chains); the run of second digit d2 goes to slab_b[(b * 256 + d2) * stride_b ...) behind the chain's
+//           earlier tiles.
+//   finish  wave_segment_sort_kernel on the bits below (its LDS passes are stable), gated by the mode word like the
+//           keys-only form; the safety net is the same cooperative LSD sort.
+// Tickets give tile indices in arrival order, so a tile only ever waits for tiles that already run.
+// ------------------------------------------------------------------------------------------
+struct StablePlace {   // written by msd2s_prep_kernel
+    uint32_t top;      // one past the highest key bit in which two sampled keys differ (>= 16)
+    uint32_t prefix;   // key >> top of every key (top < 32)
+    uint32_t low_bits; // top - 16: what the finish sorts
+    uint32_t pad;
+};
+
+// one workgroup: sample 1024 keys -> digit placement; clear the tickets of both passes
+template <typename E>
+__global__ __launch_bounds__(1024) void msd2s_prep_kernel(const E* __restrict__ src, uint32_t n, StablePlace* __restrict__ place,
+                                                           uint32_t* __restrict__ tickets, uint32_t ticket_words)
+{
+    __shared__ uint32_t s_or[16], s_and[16];
+    const int tid = (int)threadIdx.x;
+    for (uint32_t i = (uint32_t)tid; i < ticket_words; i += 1024u) tickets[i] = 0u;
+    const uint32_t v = (uint32_t)src[(size_t)((unsigned long long)tid * n / 1024ull)];   // the key is the low dword
+    uint32_t o = v, a = v;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        o |= __shfl_xor(o, sh);
+        a &= __shfl_xor(a, sh);
+    }
+    if ((tid & 63) == 0) {
+        s_or[tid >> 6] = o;
+        s_and[tid >> 6] = a;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 16; ++i) {
+            o |= s_or[i];
+            a &= s_and[i];
+        }
+        const uint32_t diff = o ^ a;
+        uint32_t top = diff ? 32u - (uint32_t)__builtin_clz(diff) : 0u;
+        if (top < 16u) top = 16u;
+        place->top = top;
+        place->prefix = top < 32u ? (o >> top) : 0u;
+        place->low_bits = top - 16u;
+    }
+}
+
+template <typename E>
+struct LookbackPass {
+    const E* src;
+    E* dst;
+    uint32_t* status;             // [chains * rows_per_chain][256] status rows, zero on entry
+    uint32_t status_bytes;
+    uint32_t* tickets;            // one counter per chain, kTicketStride words apart, zero on entry
+    uint32_t* flag;               // set when a run does not fit its slab, or a key lies outside the sampled range
+    uint32_t* fault;
+    const StablePlace* place;
+    int which_digit;              // 1: pass A, 2: pass B
+    uint32_t n;
+    uint32_t chains;              // 16 | 256
+    uint32_t rows_per_chain;      // status rows of a chain = the most tiles it can have
+    uint32_t slice;               // pass A: elements per chain (a multiple of the tile)
+    uint32_t src_stride;          // pass B: elements between two sub-slabs of pass A
+    const uint32_t* status_a;     // pass B: pass A's status rows (sub-slab sizes = last row of each of its chains) ...
+    uint32_t rows_per_chain_a;    // ... rows_per_chain of pass A
+    uint32_t dst_stride;          // elements per destination slab
+    uint32_t dst_total;
+};
+
+template <typename E, int NT, int K>
+__global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E> a)
+{
+    using C = TileCfg<E, 8, NT, K>;
+    typedef AosIO<E> IO;
+    constexpr int BINS = 256;
+    constexpr int NW = C::NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    E* __restrict__ s_elems = reinterpret_cast<E*>(smem + C::OFF_ELEMS);
+    uint32_t* __restrict__ s_wcnt = reinterpret_cast<uint32_t*>(smem + C::OFF_WCNT);   // [NW][BINS]
+    uint32_t* __restrict__ s_goff = reinterpret_cast<uint32_t*>(smem + C::OFF_GOFF);   // [BINS]
+    uint32_t* __restrict__ s_misc = reinterpret_cast<uint32_t*>(smem + C::OFF_MISC);
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const uint32_t chain = blockIdx.x % a.chains;
+    const int start_bit = (int)a.place->top - 8 * a.which_digit;
+
+    // ---- ticket -> tile index in the chain -> where the tile's elements are ------------------------------------------------
+    if (w == 0) {
+        uint32_t index = 0u;
+        if (lane == 0) index = atomicAdd(&a.tickets[chain * (uint32_t)kTicketStride], 1u);
+        index = (uint32_t)__builtin_amdgcn_readfirstlane((int)index);
+        uint32_t base = 0u, valid = 0u;
+        if (a.which_digit == 1) {
+            const uint32_t c0 = chain * a.slice;
+            const uint32_t c1 = c0 + a.slice < a.n ? c0 + a.slice : a.n;
+            const uint32_t off = index * (uint32_t)C::TILE;
+            if (c0 < a.n && off < c1 - c0) {
+                base = c0 + off;
+                valid = c1 - base < (uint32_t)C::TILE ? c1 - base : (uint32_t)C::TILE;
+            }
+        } else {
+            // sub-slab (chain, c), c = lane < 16: its size is the inclusive prefix of digit `chain` in the last row of pass A's
+            // chain c; the tile index counts tiles over the 16 sub-slabs in order
+            uint32_t cnt = 0u;
+            if (lane < 16) {
+                const uint32_t c0 = (uint32_t)lane * a.slice;
+                if (c0 < a.n) {
+                    const uint32_t len = (c0 + a.slice < a.n ? c0 + a.slice : a.n) - c0;
+                    const uint32_t rows = (len + (uint32_t)C::TILE - 1u) / (uint32_t)C::TILE;
+                    cnt = a.status_a[((size_t)lane * a.rows_per_chain_a + rows - 1u) * BINS + chain] & kValMask;
+                    if (cnt > a.src_stride) cnt = a.src_stride;   // overflowed in pass A: the flag is set, only stay in bounds
+                }
+            }
+            const uint32_t t = (cnt + (uint32_t)C::TILE - 1u) / (uint32_t)C::TILE;
+            const uint32_t incl = wave_incl_scan_u32(t);
+            const bool mine = (lane < 16) && (index >= incl - t) && (index < incl);
+            const unsigned long long m = __ballot(mine);
+            if (m) {
+                const int c = __builtin_ctzll(m);
+                const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)(incl - t), c);
+                const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, c);
+                const uint32_t off = (index - first) * (uint32_t)C::TILE;
+                base = (chain * 16u + (uint32_t)c) * a.src_stride + off;
+                valid = cc - off < (uint32_t)C::TILE ? cc - off : (uint32_t)C::TILE;
+            }
+        }
+        if (lane == 0) {
+            s_misc[0] = index;
+            s_misc[1] = base;
+            s_misc[2] = valid;
+        }
+    }
+    __syncthreads();
+    const uint32_t index = s_misc[0];
+    const uint32_t base = s_misc[1];
+    const uint32_t valid = s_misc[2];
+    if (valid == 0u) return;   // a ticket beyond the chain's tiles
+    const uint32_t first_row = chain * a.rows_per_chain;
+    const uint32_t row = first_row + index;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.status, 0, (int)a.status_bytes, 0x00020000);
+    uint32_t* my_wcnt = s_wcnt + w * BINS;
+    const IO io{a.src, a.dst};
+    const bool scaled = dst_fits32<IO>(a.dst_total);
+
+    // ---- load, wave-striped; slots beyond `valid` are all-ones pads (digit 255, highest tile positions, never stored) ----
+    const uint32_t wbase = (uint32_t)(w * 64 * K + lane);
+    E e[K];
+    {
+        const typename IO::Cursor p = io.cursor((size_t)base + wbase);
+        if (valid == (uint32_t)C::TILE) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) e[j] = p.at(j * 64);
+        } else {
+            const int rem = (int)valid - (int)wbase;
+#pragma unroll
+            for (int j = 0; j < K; ++j) e[j] = (j * 64 < rem) ? p.at(j * 64) : ~E(0);
+        }
+    }
+    if (a.which_digit == 1 && a.place->top < 32u) {   // a key outside the sampled range would land in a wrong bucket
+        const uint32_t top = a.place->top, pre = a.place->prefix;
+        const int rem = (int)valid - (int)wbase;
+        uint32_t bad = 0u;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j * 64 < rem) bad |= ((uint32_t)e[j] >> top) ^ pre;
+        if (bad) __hip_atomic_fetch_or(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- rank ---------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int b = lane; b < BINS; b += 64) my_wcnt[b] = 0u;
+    uint32_t rnk2[(K + 1) / 2];
+    {
+        uint32_t rnk[K];
+        rank_in_wave<E, 8, K, 1>(e, rnk, my_wcnt, start_bit);
+#pragma unroll
+        for (int j = 0; j < K; j += 2) rnk2[j >> 1] = rnk[j] | ((j + 1 < K ? rnk[j + 1] : 0u) << 16);
+    }
+#pragma unroll
+    for (int j = 0; j < (K + 1) / 2; ++j) asm volatile("" : "+v"(rnk2[j]));
+#pragma unroll
+    for (int j = 0; j < K; ++j) asm volatile("" : "+v"(e[j]));
+    __syncthreads();
+    // ---- every wave: counts of all waves for its lanes' digits -> tile offsets -> its own (wave, digit) positions; wave 0
+    // publishes the tile's counts at once (the chain's first tile: they are its prefix) ---------------------------------------
+    u32x4 cnt4 = {0u, 0u, 0u, 0u};
+    u32x4 toff4 = {0u, 0u, 0u, 0u};
+    uint16_t* __restrict__ my_wpos = reinterpret_cast<uint16_t*>(smem + C::OFF_WPOS) + w * BINS;
+    u32x4 real4;
+    {
+        u32x4 pre4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const u32x4 r = *reinterpret_cast<const u32x4*>(s_wcnt + i * BINS + 4 * lane);
+            cnt4 += r;
+            if (i < w) pre4 += r;
+        }
+        real4 = cnt4;
+        if (lane == 63) real4.w -= (uint32_t)C::TILE - valid;   // the pads sit under digit 255
+        if (w == 0)
+            __builtin_amdgcn_raw_buffer_store_b128(real4 | (index == 0u ? kFlagPfx : kFlagAgg), rsrc,
+                                                   (row * (uint32_t)BINS + 4u * (uint32_t)lane) * 4u, 0, 16 /* sc1 */);
+        const uint32_t s4 = cnt4.x + cnt4.y + cnt4.z + cnt4.w;
+        const uint32_t ex = wave_incl_scan_u32(s4) - s4;
+        toff4.x = ex;
+        toff4.y = ex + cnt4.x;
+        toff4.z = toff4.y + cnt4.y;
+        toff4.w = toff4.z + cnt4.z;
+        const u32x4 p4 = toff4 + pre4;
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 packed = {p4.x | (p4.y << 16), p4.z | (p4.w << 16)};
+        *reinterpret_cast<u32x2*>(my_wpos + 4 * lane) = packed;
+    }
+    // ---- scatter into tile-sorted order ---------------------------------------------------------------------------------------------
+    {
+        constexpr int CH = K < 8 ? K : 8;
+#pragma unroll
+        for (int j0 = 0; j0 < K; j0 += CH) {
+            uint32_t pos[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) pos[j] = my_wpos[digit_of<8>(e[(j0 + j < K) ? j0 + j : K - 1], start_bit)];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                if (j0 + j < K) {
+                    const uint32_t r = (rnk2[(j0 + j) >> 1] >> (16 * ((j0 + j) & 1))) & 0xffffu;
+                    s_elems[pos[j] + r] = e[j0 + j];
+                }
+            }
+        }
+    }
+    // ---- look-back (as late as possible), room check, destinations ----------------------------------------------------------
+    if (w == 0) {
+        u32x4 excl = {0u, 0u, 0u, 0u};
+        if (index != 0u) {
+            excl = lookback_exclusive4<BINS, kLookbackWindow>(rsrc, row, first_row, lane, a.fault, start_bit);
+            __builtin_amdgcn_raw_buffer_store_b128(((excl + real4) & kValMask) | kFlagPfx, rsrc,
+                                                   (row * (uint32_t)BINS + 4u * (uint32_t)lane) * 4u, 0, 16);
+        }
+        const u32x4 end4 = excl + real4;
+        const bool over = (end4.x > a.dst_stride) | (end4.y > a.dst_stride) | (end4.z > a.dst_stride) | (end4.w > a.dst_stride);
+        if (over) __hip_atomic_fetch_or(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // slab of digit d: pass A (d * 16 + chain), pass B (chain * 256 + d)
+        const uint32_t d0 = 4u * (uint32_t)lane;
+        u32x4 sl;
+        if (a.which_digit == 1) {
+            sl.x = (d0 + 0u) * 16u + chain; sl.y = (d0 + 1u) * 16u + chain; sl.z = (d0 + 2u) * 16u + chain; sl.w = (d0 + 3u) * 16u + chain;
+        } else {
+            sl.x = chain * 256u + d0; sl.y = sl.x + 1u; sl.z = sl.x + 2u; sl.w = sl.x + 3u;
+        }
+        // an overflowing run would be written beyond its slab: park it at the slab's start instead (the result is discarded)
+        u32x4 in4 = excl;
+        if (end4.x > a.dst_stride) in4.x = 0u;
+        if (end4.y > a.dst_stride) in4.y = 0u;
+        if (end4.z > a.dst_stride) in4.z = 0u;
+        if (end4.w > a.dst_stride) in4.w = 0u;
+        const u32x4 go = sl * a.dst_stride + in4 - toff4;
+        *reinterpret_cast<u32x4*>(s_goff + 4 * lane) = scaled ? go * (uint32_t)IO::kStoreScale : go;
+    }
+    __syncthreads();
+    write_out_tile<IO, 8, NT, K, ADLHIP_WRITE_UNROLL>(io, s_elems, s_goff, valid, a.dst_total, start_bit, scaled);
+}
+
+// Between pass B and the finish: workgroup b turns bucket b's final counts (the last status row of chain b) into the
+// segments' sizes and output offsets; the last workgroup publishes the mode word and the host's hint.
+template <int TILE>
+__global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __restrict__ status_a, uint32_t rows_per_chain_a, uint32_t slice,
+                                                            const uint32_t* __restrict__ status_b, uint32_t rows_per_chain_b,
+                                                            uint32_t src_stride, uint32_t* flag, uint32_t* done, uint32_t* bar,
+                                                            uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_off,
+                                                            uint32_t* __restrict__ mode, uint32_t* host_mode, uint32_t n,
+                                                            const StablePlace* __restrict__ place)
+{
+    __shared__ uint32_t s_wsum[256 / 64 + 1];
+    __shared__ uint32_t s_misc[4];
+    const int t = (int)threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    // thread t: size of bucket t = sum of its 16 sub-slabs; and the tiles pass B made of it
+    uint32_t size_t_ = 0u, tiles_t = 0u;
+    for (uint32_t c = 0; c < 16u; ++c) {
+        const uint32_t c0 = c * slice;
+        if (c0 >= n) break;
+        const uint32_t len = (c0 + slice < n ? c0 + slice : n) - c0;
+        const uint32_t rows = (len + (uint32_t)TILE - 1u) / (uint32_t)TILE;
+        uint32_t cnt = status_a[((size_t)c * rows_per_chain_a + rows - 1u) * 256u + (uint32_t)t] & kValMask;
+        if (cnt > src_stride) cnt = src_stride;
+        size_t_ += cnt;
+        tiles_t += (cnt + (uint32_t)TILE - 1u) / (uint32_t)TILE;
+    }
+    const uint32_t exa = block_excl_scan_u32<256>(size_t_, s_wsum, nullptr);
+    if (t == (int)b) {
+        s_misc[0] = exa;
+        s_misc[1] = tiles_t;
+    }
+    __syncthreads();
+    const uint32_t tiles_b = s_misc[1];
+    const uint32_t cb = tiles_b ? (status_b[((size_t)b * rows_per_chain_b + tiles_b - 1u) * 256u + (uint32_t)t] & kValMask) : 0u;
+    const uint32_t exb = block_excl_scan_u32<256>(cb, s_wsum, nullptr);
+    seg_cnt[b * 256u + (uint32_t)t] = cb;
+    seg_off[b * 256u + (uint32_t)t] = s_misc[0] + exb;
+    if (t == 0) s_misc[2] = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_misc[2] == gridDim.x - 1u && t == 0) {
+        const uint32_t f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *mode = f ? 1u : 0u;
+        mode[kDynLowBits] = place->low_bits;
+        seg_off[65536] = n;
+        __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(host_mode, 1u + (f ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

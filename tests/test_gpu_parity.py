@@ -1126,6 +1126,7 @@ def test_large_keys_only_sort_two_msd_passes_and_lds_finish(dev):
             "one eighth of the key range (a rank of an 8-GPU sort)": (u >> np.uint32(3)) | np.uint32(0xa0000000),
             "below 2^28": u >> np.uint32(4),
             "below 2^20": u >> np.uint32(12),
+            "below 2^16 (nothing left for the finish)": u >> np.uint32(16),
             "range that is not a power of two": (u % np.uint32(3 << 27)) + np.uint32(1 << 30),
         }
         for nm, k in narrow.items():
@@ -1164,6 +1165,7 @@ def test_large_keys_only_sort_u64_keys(dev):
             "top 28 bits unused": u >> np.uint64(28),
             "values below 2^32": u >> np.uint64(32),
             "values below 2^20": u >> np.uint64(44),
+            "values below 2^16 (nothing left for the finish)": u >> np.uint64(48),
             "constant high dword": (u & np.uint64(0xffffffff)) | np.uint64(0x1234567800000000),
             "constant low dword": (u & np.uint64(0xffffffff00000000)) | np.uint64(0x9abcdef0),
             "all equal": np.full(n, 0xdeadbeefcafef00d, dtype=np.uint64),
@@ -1192,3 +1194,45 @@ def test_large_keys_only_sort_beyond_64mi(dev, pp, n):
     del keys
     assert np.array_equal(got, want)
     dev.checkFault()
+
+
+def test_large_pairs_stable_msd_passes_with_lookback(dev):
+    """{key, value} pairs on the large path: the two MSD passes place tiles by look-back (stable), the LDS finish is stable,
+    so equal keys keep their input order -- bit-exact against the oracle's stable sort, on keys with many duplicates too.
+    Keys that do not fit the slabs go to the safety net."""
+    dev.setParam("sort.msd2", 2)
+    p = Pprims()
+    try:
+        for n in ((1 << 20) + 77, 3000001, 1 << 24, (1 << 25) + 12345):
+            pairs = oracle.pairs_kv32(n, seed=n & 0xff)
+            assert np.array_equal(gpu_sort_kv(dev, p, pairs), oracle.sort_kv32(pairs)), ("uniform", n)
+        n = (1 << 23) + 11
+        pr = oracle.pairs_kv32(n, seed=7)
+        key = pr & np.uint64(0xffffffff)
+        val = pr & np.uint64(0xffffffff00000000)
+        cases = {
+            "20-bit keys (every key ~8 times)": val | (key >> np.uint64(12)),
+            "16-bit keys": val | (key >> np.uint64(16)),
+            "keys in one eighth of the range": val | (key >> np.uint64(3)) | np.uint64(0x60000000),
+            "low byte constant": val | (key & np.uint64(0xffffff00)),
+            "all keys equal": val | np.uint64(0x12345678),
+            "sorted keys": val | np.sort(key),
+            "one heavy top byte": val | np.where(np.arange(n) % 10 != 0, key >> np.uint64(8), key),
+        }
+        for nm, pairs in cases.items():
+            pairs = pairs.astype(np.uint64)
+            assert np.array_equal(gpu_sort_kv(dev, p, pairs), oracle.sort_kv32(pairs)), nm
+        pairs = (val | (key >> np.uint64(10))).astype(np.uint64)   # outliers above the sampled range
+        pairs[4321] |= np.uint64(0xf0000000)
+        pairs[n - 5] |= np.uint64(0x80000000)
+        assert np.array_equal(gpu_sort_kv(dev, p, pairs), oracle.sort_kv32(pairs)), "outliers"
+        DeviceUtils.waitForCompletion(dev)
+        dev.setParam("sort.msd2", 1)
+        for i in range(4):   # the automatic choice, friendly and skewed inputs alternating
+            pairs = oracle.pairs_kv32(n, seed=30 + i)
+            if i % 2:
+                pairs = (pairs & np.uint64(0xffffffff00000000)) | ((pairs & np.uint64(0xffffffff)) % np.uint64(1000))
+            assert np.array_equal(gpu_sort_kv(dev, p, pairs), oracle.sort_kv32(pairs)), i
+    finally:
+        dev.setParam("sort.msd2", 1)
+        p.close()
