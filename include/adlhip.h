@@ -131,7 +131,9 @@ int adlhip_unmap(adlhip_device* dev, void* dptr, void* hptr, size_t bytes);
 /* Scratch the caller must own, replacing Pprims' m_u32WorkBuffer[0] (ping-pong copy of the data,
  * Pprims.cpp:226-232, :332) and m_u32WorkBuffer[1] (histogram table, :229-230, :333-337).
  *   *tmp_bytes  : second data buffer, n elements
- *   *work_bytes : control scratch (digit tables / tile status words), depends on n and the device.  The value
+ *   *work_bytes : control scratch (digit tables / tile status words) and, for the sizes the large sort takes
+ *                 ("sort.msd2": full-key sorts of more than 1 Mi elements), its bucket and segment slabs -- about
+ *                 2.3 x n elements (64 Mi u32 keys: 0.62 GB; 64 Mi pairs: 1.3 GB; 256 Mi u64 keys: 4.9 GB).  The value
  *                 suffices for EVERY n' <= n with the current knobs (the need of a single n is not monotone:
  *                 smaller inputs use smaller tiles and so more status rows), so a caller may size its scratch
  *                 once for its largest batch; changing "sort.tile", "sort.digit_bits" or "sort.algo" later can
@@ -260,7 +262,9 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
 
 /* Integer tunables, by name.  Unknown names fail.  Current names:
  *   "sort.algo"        -1 [default] = by size: n <= 16384 one workgroup does the whole sort in one launch;
- *                      below 24 MiB of data the three-kernel pass; from there on the one-sweep path
+ *                      n <= 2 Mi the mid-size sort ("sort.mid"), above it the large sort ("sort.msd2"); for what
+ *                      those do not take (partial sort_bits, SoA, keys their hints have sent back): below
+ *                      24 MiB of data the three-kernel pass, from there on the one-sweep path
  *                      0 = onesweep (one sweep per digit, 16 decoupled look-back chains)
  *                      1 = three kernels per pass: count -> table scan -> sort+scatter (the
  *                          reference's pass structure, Pprims.cpp:357-398)
@@ -284,6 +288,14 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      device and sorted by a cooperative LSD sort inside the same launches (correct, slower);
  *                      the handle then steers later sorts by asynchronous hints (speed only; results never
  *                      depend on them).  2 / 3 force the two- / three-launch form (tests)
+ *   "sort.msd2"        1 [default] / 0: full-key sorts of 2 Mi .. 280 Mi u32 keys, 2 Mi .. 260 Mi u64 keys and
+ *                      6 Mi .. 260 Mi pairs take two MSD passes into slabs of the work buffer plus one finish in
+ *                      LDS (six moves of every element instead of nine); where the two digits sit is chosen on the
+ *                      device from a sample of the keys.  Keys only: runs are placed with atomic cursors (equal
+ *                      keys are indistinguishable); pairs: by look-back, stably.  Keys that do not fit the slabs
+ *                      are detected on the device and sorted by a cooperative LSD sort in one further launch
+ *                      (correct, slower); asynchronous hints then keep such a handle on the per-digit passes
+ *                      (speed only).  2 forces the path from 1 Mi elements (tests)
  *   "profile"          0/1: bracket every kernel launch with hipEvents (Device::toggleProfiling,
  *                          Adl/Adl.h:142, AdlKernelUtilsCL.inl:654-677) */
 int adlhip_set_param(adlhip_device* dev, const char* name, int value);

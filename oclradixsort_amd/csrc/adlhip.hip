@@ -1017,25 +1017,38 @@ constexpr uint32_t kMsd2sTile = 8192;               // TileCfg<uint64_t, 8, 512,
 
 struct Msd2sLayout {
     size_t off_mode, off_place, off_cnt, off_off, off_coop, off_tickets, off_status_a, off_status_b, off_slab_a, off_slab_b, total;
-    uint32_t slice, rows_a, rows_b, stride_a, stride_b, ticket_words;
+    uint32_t pieces, slice, rows_a, rows_b, stride_a, stride_b, ticket_words;
     size_t status_bytes_a, status_bytes_b;
 };
 
 Msd2sLayout msd2s_layout(size_t n)
 {
     Msd2sLayout L;
-    L.slice = (uint32_t)align_up((n + 15) / 16, kMsd2sTile);            // elements per chain of pass A
-    L.rows_a = L.slice / kMsd2sTile;
-    {   // sub-slab (digit, chain): mean slice / 256 + 8 standard deviations
-        const size_t mean = L.slice / 256;
+    // pieces = chains of pass A = sub-slabs per bucket.  16 = twice the number of XCDs: workgroup i runs on XCD i % 8 and takes
+    // chain i % 16, so a chain's tiles stay on ONE XCD -- its status rows and the abutting runs of consecutive tiles meet in
+    // that XCD's L2.  Chain counts that break this measured slower although they make pass B's tiles fuller (64 Mi pairs,
+    // pass A / pass B: 16 chains 0.252 / 0.309 ms, 12 chains 0.282 / 0.325, 18 chains 0.303 / 0.324).  The code below keeps
+    // the choice open (any count up to 24 works).
+    double best = 1e30;
+    for (uint32_t p : {16u}) {
+        const size_t slice = align_up((n + p - 1) / p, kMsd2sTile);
+        const size_t mean = slice / 256;
         size_t sd = 1;
         while (sd * sd < mean) ++sd;
-        L.stride_a = (uint32_t)align_up(mean + 8 * sd + 64, 64);
+        const size_t stride = align_up(mean + 8 * sd + 64, 64);
+        const double waste = (double)((stride + kMsd2sTile - 1) / kMsd2sTile) * kMsd2sTile / (double)mean;
+        if (waste < best - 1e-9) {
+            best = waste;
+            L.pieces = p;
+            L.slice = (uint32_t)slice;
+            L.stride_a = (uint32_t)stride;
+        }
     }
-    L.rows_b = 16u * ((L.stride_a + kMsd2sTile - 1) / kMsd2sTile);     // the most tiles a bucket can have
+    L.rows_a = L.slice / kMsd2sTile;
+    L.rows_b = L.pieces * ((L.stride_a + kMsd2sTile - 1) / kMsd2sTile);   // the most tiles a bucket can have
     L.stride_b = msd2_stride_b(n);
-    L.ticket_words = (16 + 256) * adlhip::kTicketStride;
-    L.status_bytes_a = (size_t)16 * L.rows_a * 1024;
+    L.ticket_words = (32 + 256) * adlhip::kTicketStride;
+    L.status_bytes_a = (size_t)L.pieces * L.rows_a * 1024;
     L.status_bytes_b = (size_t)256 * L.rows_b * 1024;
     L.off_mode = 0;
     L.off_place = 128;
@@ -1043,11 +1056,21 @@ Msd2sLayout msd2s_layout(size_t n)
     L.off_off = L.off_cnt + 65536 * 4;
     L.off_coop = align_up(L.off_off + 65537 * 4, 256);
     L.off_tickets = align_up(L.off_coop + (size_t)256 * 256 * 4 + 1024, 256);
+    // the regions are sized by bounds that do not depend on `pieces` and grow with n, so that the scratch for n suffices
+    // for every smaller n (adlhip_radix_sort_scratch_bytes): sub-slabs of a bucket together <= n/256 + 16 * (head-room),
+    // rows of pass A <= n/tile + 16, rows of a bucket in pass B <= its sub-slabs / tile + 16
+    size_t sdb = 1;
+    while (sdb * sdb * 4096 < n) ++sdb;   // >= sd of every choice (a sub-slab's mean is at most n / 4096 + 32)
+    const size_t bucket_bound = n / 256 + 24 * (32 + 8 * (sdb + 1) + 128);
+    const size_t rows_a_bound = n / kMsd2sTile + 24;
+    const size_t rows_b_bound = bucket_bound / kMsd2sTile + 25;
     L.off_status_a = align_up(L.off_tickets + (size_t)L.ticket_words * 4, 256);
-    L.off_status_b = L.off_status_a + L.status_bytes_a;
-    L.off_slab_a = align_up(L.off_status_b + L.status_bytes_b, 256);
-    L.off_slab_b = align_up(L.off_slab_a + (size_t)4096 * L.stride_a * 8, 256);
+    L.off_status_b = L.off_status_a + rows_a_bound * 1024;
+    L.off_slab_a = align_up(L.off_status_b + 256 * rows_b_bound * 1024, 256);
+    L.off_slab_b = align_up(L.off_slab_a + 256 * bucket_bound * 8, 256);
     L.total = L.off_slab_b + (size_t)65536 * L.stride_b * 8;
+    if ((size_t)L.pieces * L.rows_a > rows_a_bound || L.rows_b > rows_b_bound || (size_t)L.pieces * L.stride_a > bucket_bound)
+        L.total = 0;   // cannot happen; msd2s_sort refuses
     return L;
 }
 
@@ -1070,6 +1093,7 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     uint32_t* done = flag + 1;
     uint32_t* bar = flag + 2;
     const Msd2sLayout L = msd2s_layout(n);
+    if (L.total == 0) return fail("internal: layout bounds of the stable large sort");
     char* wb = reinterpret_cast<char*>(work);
     uint32_t* mode = reinterpret_cast<uint32_t*>(wb + L.off_mode);
     adlhip::StablePlace* place = reinterpret_cast<adlhip::StablePlace*>(wb + L.off_place);
@@ -1085,7 +1109,7 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     auto kern = adlhip::msd_lookback_scatter_kernel<E, 512, 16>;
     if (ensure_lds(kern, CT::LDS_BYTES)) return ADLHIP_FAILURE;
     // status rows of both passes: zero (one memset; the rows are contiguous)
-    HIPCHK(hipMemsetAsync(status_a, 0, L.status_bytes_a + L.status_bytes_b, d->stream));
+    HIPCHK(hipMemsetAsync(status_a, 0, (L.off_status_b - L.off_status_a) + L.status_bytes_b, d->stream));
     int rc = launch(d, "msd2s_prep", [&] {
         hipLaunchKernelGGL(adlhip::msd2s_prep_kernel<E>, dim3(1), dim3(1024), 0, d->stream, (const E*)data, (uint32_t)n, place, tickets,
                            L.ticket_words);
@@ -1093,16 +1117,16 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     if (rc) return rc;
     adlhip::LookbackPass<E> pa;
     pa.src = data; pa.dst = slab_a; pa.status = status_a; pa.status_bytes = (uint32_t)L.status_bytes_a; pa.tickets = tickets;
-    pa.flag = flag; pa.fault = d->d_fault; pa.place = place; pa.which_digit = 1; pa.n = (uint32_t)n; pa.chains = 16;
+    pa.flag = flag; pa.fault = d->d_fault; pa.place = place; pa.which_digit = 1; pa.n = (uint32_t)n; pa.chains = L.pieces; pa.pieces = L.pieces;
     pa.rows_per_chain = L.rows_a; pa.slice = L.slice; pa.src_stride = 0; pa.status_a = nullptr; pa.rows_per_chain_a = 0;
-    pa.dst_stride = L.stride_a; pa.dst_total = 4096u * L.stride_a;
+    pa.dst_stride = L.stride_a; pa.dst_total = 256u * L.pieces * L.stride_a;
     rc = launch(d, "msd2s_pass1_kv32", [&] {
-        hipLaunchKernelGGL(kern, dim3(16 * L.rows_a), dim3(512), CT::LDS_BYTES, d->stream, pa);
+        hipLaunchKernelGGL(kern, dim3(L.pieces * L.rows_a), dim3(512), CT::LDS_BYTES, d->stream, pa);
     });
     if (rc) return rc;
     adlhip::LookbackPass<E> pb = pa;
     pb.src = slab_a; pb.dst = slab_b; pb.status = status_b; pb.status_bytes = (uint32_t)L.status_bytes_b;
-    pb.tickets = tickets + 16 * adlhip::kTicketStride; pb.which_digit = 2; pb.chains = 256; pb.rows_per_chain = L.rows_b;
+    pb.tickets = tickets + 32 * adlhip::kTicketStride; pb.which_digit = 2; pb.chains = 256; pb.rows_per_chain = L.rows_b;
     pb.src_stride = L.stride_a; pb.status_a = status_a; pb.rows_per_chain_a = L.rows_a; pb.dst_stride = L.stride_b;
     pb.dst_total = 65536u * L.stride_b;
     rc = launch(d, "msd2s_pass2_kv32", [&] {
@@ -1111,7 +1135,7 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     if (rc) return rc;
     rc = launch(d, "msd2s_offsets", [&] {
         hipLaunchKernelGGL(adlhip::msd2s_offsets_kernel<CT::TILE>, dim3(256), dim3(256), 0, d->stream, (const uint32_t*)status_a, L.rows_a,
-                           L.slice, (const uint32_t*)status_b, L.rows_b, L.stride_a, flag, done, bar, seg_cnt, seg_off, mode,
+                           L.slice, L.pieces, (const uint32_t*)status_b, L.rows_b, L.stride_a, flag, done, bar, seg_cnt, seg_off, mode,
                            d->h_fault + 11, (uint32_t)n, (const adlhip::StablePlace*)place);
     });
     if (rc) return rc;

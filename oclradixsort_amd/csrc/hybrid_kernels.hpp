@@ -778,10 +778,11 @@ __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, 
 // learns where its run of a digit goes by decoupled LOOK-BACK over the tiles before it in its chain (the one-sweep pass's
 // status rows and lookback_exclusive4, onesweep_kernels.hpp) -- and since every (digit, chain) pair has a slab of its own,
 // no histogram and no offset table is needed:
-//   pass A  16 chains = 16 equal slices of the input (in order); the run of digit d of a tile of chain c goes to sub-slab
-//           (d, c) = slab_a[(d * 16 + c) * stride_a ...) behind the runs of the chain's earlier tiles.  Bucket d = its 16
+//   pass A  P = 16 chains = 16 equal slices of the input (in order; workgroup i takes chain i % 16 and runs on XCD i % 8, so a
+//           chain stays on one XCD); the run of digit d of a tile of chain c goes to sub-slab
+//           (d, c) = slab_a[(d * P + c) * stride_a ...) behind the runs of the chain's earlier tiles.  Bucket d = its P
 //           sub-slabs in order: input order is kept.
-//   pass B  256 chains = the buckets; chain b's tiles walk its 16 sub-slabs in order (their sizes are the last status rows of
+//   pass B  256 chains = the buckets; chain b's tiles walk its P sub-slabs in order (their sizes are the last status rows of
 //           pass A's chains); the run of second digit d2 goes to slab_b[(b * 256 + d2) * stride_b ...) behind the chain's
 //           earlier tiles.
 //   finish  wave_segment_sort_kernel on the bits below (its LDS passes are stable), gated by the mode word like the
@@ -841,7 +842,8 @@ struct LookbackPass {
     const StablePlace* place;
     int which_digit;              // 1: pass A, 2: pass B
     uint32_t n;
-    uint32_t chains;              // 16 | 256
+    uint32_t chains;              // pass A: pieces | pass B: 256
+    uint32_t pieces;              // chains of pass A = sub-slabs per bucket (16; up to 32 would work)
     uint32_t rows_per_chain;      // status rows of a chain = the most tiles it can have
     uint32_t slice;               // pass A: elements per chain (a multiple of the tile)
     uint32_t src_stride;          // pass B: elements between two sub-slabs of pass A
@@ -884,10 +886,10 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
                 valid = c1 - base < (uint32_t)C::TILE ? c1 - base : (uint32_t)C::TILE;
             }
         } else {
-            // sub-slab (chain, c), c = lane < 16: its size is the inclusive prefix of digit `chain` in the last row of pass A's
+            // sub-slab (chain, c), c = lane < pieces (<= 32): its size is the inclusive prefix of digit `chain` in the last row of pass A's
             // chain c; the tile index counts tiles over the 16 sub-slabs in order
             uint32_t cnt = 0u;
-            if (lane < 16) {
+            if ((uint32_t)lane < a.pieces) {
                 const uint32_t c0 = (uint32_t)lane * a.slice;
                 if (c0 < a.n) {
                     const uint32_t len = (c0 + a.slice < a.n ? c0 + a.slice : a.n) - c0;
@@ -898,14 +900,14 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
             }
             const uint32_t t = (cnt + (uint32_t)C::TILE - 1u) / (uint32_t)C::TILE;
             const uint32_t incl = wave_incl_scan_u32(t);
-            const bool mine = (lane < 16) && (index >= incl - t) && (index < incl);
+            const bool mine = ((uint32_t)lane < a.pieces) && (index >= incl - t) && (index < incl);
             const unsigned long long m = __ballot(mine);
             if (m) {
                 const int c = __builtin_ctzll(m);
                 const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)(incl - t), c);
                 const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, c);
                 const uint32_t off = (index - first) * (uint32_t)C::TILE;
-                base = (chain * 16u + (uint32_t)c) * a.src_stride + off;
+                base = (chain * a.pieces + (uint32_t)c) * a.src_stride + off;
                 valid = cc - off < (uint32_t)C::TILE ? cc - off : (uint32_t)C::TILE;
             }
         }
@@ -1023,11 +1025,12 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
         const u32x4 end4 = excl + real4;
         const bool over = (end4.x > a.dst_stride) | (end4.y > a.dst_stride) | (end4.z > a.dst_stride) | (end4.w > a.dst_stride);
         if (over) __hip_atomic_fetch_or(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // slab of digit d: pass A (d * 16 + chain), pass B (chain * 256 + d)
+        // slab of digit d: pass A (d * pieces + chain), pass B (chain * 256 + d)
         const uint32_t d0 = 4u * (uint32_t)lane;
         u32x4 sl;
         if (a.which_digit == 1) {
-            sl.x = (d0 + 0u) * 16u + chain; sl.y = (d0 + 1u) * 16u + chain; sl.z = (d0 + 2u) * 16u + chain; sl.w = (d0 + 3u) * 16u + chain;
+            sl.x = (d0 + 0u) * a.pieces + chain; sl.y = (d0 + 1u) * a.pieces + chain; sl.z = (d0 + 2u) * a.pieces + chain;
+            sl.w = (d0 + 3u) * a.pieces + chain;
         } else {
             sl.x = chain * 256u + d0; sl.y = sl.x + 1u; sl.z = sl.x + 2u; sl.w = sl.x + 3u;
         }
@@ -1048,6 +1051,7 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
 // segments' sizes and output offsets; the last workgroup publishes the mode word and the host's hint.
 template <int TILE>
 __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __restrict__ status_a, uint32_t rows_per_chain_a, uint32_t slice,
+                                                            uint32_t pieces,
                                                             const uint32_t* __restrict__ status_b, uint32_t rows_per_chain_b,
                                                             uint32_t src_stride, uint32_t* flag, uint32_t* done, uint32_t* bar,
                                                             uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_off,
@@ -1060,7 +1064,7 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
     const uint32_t b = blockIdx.x;
     // thread t: size of bucket t = sum of its 16 sub-slabs; and the tiles pass B made of it
     uint32_t size_t_ = 0u, tiles_t = 0u;
-    for (uint32_t c = 0; c < 16u; ++c) {
+    for (uint32_t c = 0; c < pieces; ++c) {
         const uint32_t c0 = c * slice;
         if (c0 >= n) break;
         const uint32_t len = (c0 + slice < n ? c0 + slice : n) - c0;
