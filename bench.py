@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--digit-bits", type=int, default=None, help="sort.digit_bits override (8 or 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config #3 / #5 extras beside the metric")
     args = ap.parse_args()
 
     import torch
@@ -224,6 +225,43 @@ def main():
         digit_bits = d.getParam("sort.digit_bits")
         for b in bufs:
             b.release()
+
+        # BASELINE configs #3 and #5 beside the metric (not part of it): a few sorts each, fresh random inputs, device time
+        # between two events on the library's stream; sortedness + checksum of one result checked outside the timing
+        others = {}
+        if n == N_KEYS and not args.no_other_configs:
+            for label, nn, dtype, gen, unit, sorter in (
+                    ("config3_key_value_64Mi_pairs", 1 << 26, np.uint64, 1, "Gpairs/s", lambda b, m: p.radixSort(d, b, m)),
+                    ("config5_u64_256Mi_keys", 1 << 28, np.uint64, 2, "Gkeys/s", lambda b, m: p.radixSort64(d, b, m))):
+                try:
+                    reps = 4
+                    bb = [Buffer(d, nn, dtype) for _ in range(reps + 1)]
+                    for i, b in enumerate(bb):
+                        b.generate(nn, seed=900 + i, kind=gen)
+                    sorter(bb[0], nn)
+                    DeviceUtils.waitForCompletion(d)
+                    s3 = Stopwatch(d)
+                    s3.start()
+                    for b in bb[1:]:
+                        sorter(b, nn)
+                    s3.stop()
+                    ms = s3.getMs() / reps
+                    entry = {"value": nn / ms / 1e6, "unit": unit, "ms_per_sort": ms, "elements": nn, "sorts_timed": reps}
+                    if not args.no_verify:
+                        got = bb[1].toHost()
+                        keys = (got & np.uint64(0xffffffff)) if gen == 1 else got
+                        entry["sorted"] = bool(np.all(keys[1:] >= keys[:-1]))
+                        if gen == 1:   # stability: values are the input indices, so they rise within a run of equal keys
+                            same = keys[1:] == keys[:-1]
+                            vals = got >> np.uint64(32)
+                            entry["stable"] = bool(np.all(vals[1:][same] > vals[:-1][same]))
+                        del got, keys
+                    for b in bb:
+                        b.release()
+                    others[label] = entry
+                except Exception as e:   # never lose the metric over an extra
+                    others[label] = {"error": repr(e)[:300]}
+        out["other_configs"] = others
         p.close()
         info_name = d.getDeviceName()
         DeviceUtils.deallocate(d)

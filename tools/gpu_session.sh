@@ -28,7 +28,7 @@ cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format cs
 for f in $(find $OUT/prof_stats -name "*kernel_stats.csv"); do cp $f $OUT/bench_kernel_stats.csv; head -6 $f | cut -c1-180; done
 echo "== PMC passes (separate runs, --kernel-trace only)"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-verify > $OUT/pmc_$c.log 2>&1
+  timeout -k 10 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-verify --no-other-configs > $OUT/pmc_$c.log 2>&1
 done
 cd $GRAFT_REPO_ROOT && python3 tools/pmc_summary.py $OUT | tee $OUT/pmc_summary.txt | grep -A3 -E "onesweep_chain|msd_bucket"
 python3 tools/pmc_traffic.py $OUT $OUT/pmc_traffic.json
