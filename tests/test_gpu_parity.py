@@ -705,6 +705,25 @@ def test_generated_keys_match_the_oracle_generator(dev):
         b.release()
 
 
+def test_scratch_bytes_never_shrink_with_n(dev):
+    """adlhip_radix_sort_scratch_bytes(n) suffices for every smaller n (include/adlhip.h): a caller sizes its scratch once for
+    its largest batch.  Checked as monotonicity over sizes around every threshold at which a path or a tile changes."""
+    import ctypes
+    from oclradixsort_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    edges = [1 << k for k in range(10, 29)] + [(2 << 20) + 1, (6 << 20) + 1, (1 << 26) + (1 << 20), 280 << 20, (280 << 20) + 1,
+                                              (1 << 28) + (1 << 22), (1 << 28) + (1 << 22) + 1, 3 << 20, 24 << 18, 3 << 27]
+    sizes = sorted(set(edges + [e - 1 for e in edges] + [int(x) for x in rng.integers(1 << 10, 3 << 27, 300)]))
+    for kind in (0, 1, 2, 3):
+        last_t = last_w = 0
+        for n in sizes:
+            tb, wb = ctypes.c_size_t(), ctypes.c_size_t()
+            assert lib.adlhip_radix_sort_scratch_bytes(dev._h, kind, n, ctypes.byref(tb), ctypes.byref(wb)) == 0
+            assert tb.value >= last_t and wb.value >= last_w, (kind, n, wb.value, last_w)
+            last_t, last_w = tb.value, wb.value
+
+
 def test_abi_argument_validation(dev):
     """The C ABI refuses bad buffers loudly instead of launching kernels on them."""
     import ctypes
