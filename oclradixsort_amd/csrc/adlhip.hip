@@ -1045,7 +1045,8 @@ Msd2sLayout msd2s_layout(size_t n)
         }
     }
     L.rows_a = L.slice / kMsd2sTile;
-    L.rows_b = L.pieces * ((L.stride_a + kMsd2sTile - 1) / kMsd2sTile);   // the most tiles a bucket can have
+    // the most tiles a bucket can have: pass B's tiles run across the sub-slabs, and a sub-slab holds at most its stride
+    L.rows_b = (uint32_t)(((size_t)L.pieces * L.stride_a + kMsd2sTile - 1) / kMsd2sTile);
     L.stride_b = msd2_stride_b(n);
     L.ticket_words = (32 + 256) * adlhip::kTicketStride;
     L.status_bytes_a = (size_t)L.pieces * L.rows_a * 1024;

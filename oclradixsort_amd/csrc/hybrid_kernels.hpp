@@ -782,8 +782,8 @@ __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, 
 //           chain stays on one XCD); the run of digit d of a tile of chain c goes to sub-slab
 //           (d, c) = slab_a[(d * P + c) * stride_a ...) behind the runs of the chain's earlier tiles.  Bucket d = its P
 //           sub-slabs in order: input order is kept.
-//   pass B  256 chains = the buckets; chain b's tiles walk its P sub-slabs in order (their sizes are the last status rows of
-//           pass A's chains); the run of second digit d2 goes to slab_b[(b * 256 + d2) * stride_b ...) behind the chain's
+//   pass B  256 chains = the buckets; chain b's tiles are consecutive stretches of its P sub-slabs taken one after the other
+//           (the sub-slabs' sizes are the last status rows of pass A's chains; a tile may start in one and end in the next); the run of second digit d2 goes to slab_b[(b * 256 + d2) * stride_b ...) behind the chain's
 //           earlier tiles.
 //   finish  wave_segment_sort_kernel on the bits below (its LDS passes are stable), gated by the mode word like the
 //           keys-only form; the safety net is the same cooperative LSD sort.
@@ -898,18 +898,30 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
                     if (cnt > a.src_stride) cnt = a.src_stride;   // overflowed in pass A: the flag is set, only stay in bounds
                 }
             }
-            const uint32_t t = (cnt + (uint32_t)C::TILE - 1u) / (uint32_t)C::TILE;
-            const uint32_t incl = wave_incl_scan_u32(t);
-            const bool mine = ((uint32_t)lane < a.pieces) && (index >= incl - t) && (index < incl);
-            const unsigned long long m = __ballot(mine);
-            if (m) {
-                const int c = __builtin_ctzll(m);
-                const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)(incl - t), c);
-                const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, c);
-                const uint32_t off = (index - first) * (uint32_t)C::TILE;
-                base = (chain * a.pieces + (uint32_t)c) * a.src_stride + off;
-                valid = cc - off < (uint32_t)C::TILE ? cc - off : (uint32_t)C::TILE;
+            // a tile is C::TILE consecutive elements of the bucket = of its sub-slabs one after the other: it may start in one
+            // sub-slab and end in another (tiles cut at sub-slab ends left every second sub-slab of 64 Mi pairs with a third,
+            // nearly empty tile, and small inputs with nothing but part-filled tiles).  Tables for the load below, in the
+            // s_goff area (written again only after the barrier behind the ranking): where sub-slab c ends in the bucket,
+            // and what turns a position in the bucket into an index into slab_a.
+            const uint32_t incl = wave_incl_scan_u32(cnt);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (lane < 32) {
+                const bool real = (uint32_t)lane < a.pieces;
+                s_goff[lane] = real ? incl : 0xffffffffu;
+                s_goff[32 + lane] = real ? (chain * a.pieces + (uint32_t)lane) * a.src_stride - (incl - cnt) : 0u;
             }
+            base = index * (uint32_t)C::TILE;   // position in the bucket
+            if (base < total) valid = total - base < (uint32_t)C::TILE ? total - base : (uint32_t)C::TILE;
+            // a tile that lies inside ONE sub-slab (most tiles of a large input) is loaded like a tile of pass A
+            const bool holds = (uint32_t)lane < a.pieces && base >= incl - cnt && base + valid <= incl && valid != 0u;
+            const unsigned long long hm = __ballot(holds);
+            uint32_t lin = 0xffffffffu;
+            if (hm) {
+                const int c = __builtin_ctzll(hm);
+                const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)(incl - cnt), c);
+                lin = (chain * a.pieces + (uint32_t)c) * a.src_stride + (base - first);
+            }
+            if (lane == 0) s_misc[3] = lin;
         }
         if (lane == 0) {
             s_misc[0] = index;
@@ -932,8 +944,9 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
     // ---- load, wave-striped; slots beyond `valid` are all-ones pads (digit 255, highest tile positions, never stored) ----
     const uint32_t wbase = (uint32_t)(w * 64 * K + lane);
     E e[K];
-    {
-        const typename IO::Cursor p = io.cursor((size_t)base + wbase);
+    const uint32_t lin = a.which_digit == 1 ? base : s_misc[3];   // index of the tile's first element if it is one stretch
+    if (lin != 0xffffffffu) {
+        const typename IO::Cursor p = io.cursor((size_t)lin + wbase);
         if (valid == (uint32_t)C::TILE) {
 #pragma unroll
             for (int j = 0; j < K; ++j) e[j] = p.at(j * 64);
@@ -941,6 +954,20 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
             const int rem = (int)valid - (int)wbase;
 #pragma unroll
             for (int j = 0; j < K; ++j) e[j] = (j * 64 < rem) ? p.at(j * 64) : ~E(0);
+        }
+    } else {
+        // position in the bucket -> sub-slab: found once for the lane's first element, then carried along (positions rise)
+        const uint32_t* __restrict__ s_end = s_goff;
+        const uint32_t* __restrict__ s_adj = s_goff + 32;
+        const uint32_t q0 = base + wbase;
+        uint32_t c = 0u;
+        for (uint32_t i = 0; i < a.pieces; ++i) c += (q0 >= s_end[i]) ? 1u : 0u;
+        const int rem = (int)valid - (int)wbase;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t q = q0 + (uint32_t)(j * 64);
+            while (c < 31u && q >= s_end[c]) ++c;
+            e[j] = (j * 64 < rem) ? a.src[(size_t)(q + s_adj[c])] : ~E(0);
         }
     }
     if (a.which_digit == 1 && a.place->top < 32u) {   // a key outside the sampled range would land in a wrong bucket
@@ -1072,8 +1099,8 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
         uint32_t cnt = status_a[((size_t)c * rows_per_chain_a + rows - 1u) * 256u + (uint32_t)t] & kValMask;
         if (cnt > src_stride) cnt = src_stride;
         size_t_ += cnt;
-        tiles_t += (cnt + (uint32_t)TILE - 1u) / (uint32_t)TILE;
     }
+    tiles_t = (size_t_ + (uint32_t)TILE - 1u) / (uint32_t)TILE;   // pass B's tiles run across the sub-slabs
     const uint32_t exa = block_excl_scan_u32<256>(size_t_, s_wsum, nullptr);
     if (t == (int)b) {
         s_misc[0] = exa;

@@ -4,7 +4,8 @@ element kinds and key distributions, every result checked (sortedness + multiset
 result copied back, full oracle comparison for the smaller ones), fault word checked at every sync.  Every eighth sort
 is followed -- while later sorts are already queued -- by the LDS-order self-test on a SECOND handle (the hardware
 behaviour "sort.rank" = 1 rests on, adlhip_selftest_lds_order), and one size class reaches past 64 Mi keys (the
-pointer-store write-out).
+pointer-store write-out).  Half of the sorts take the automatic choice (mid-size sort, large sort with its look-back /
+cursor passes, hints and safety net), with "sort.msd2" forced on for some and keys shifted down by a random number of bits.
    python tools/stress.py [--seconds 60]"""
 import argparse, os, sys, time
 import numpy as np
@@ -26,15 +27,20 @@ while time.time() < t_end:
     it += 1
     kind = rng.choice(["u32", "kv", "u64", "soa"])
     n = int(2 ** rng.uniform(10, 25.5)) + int(rng.randint(0, 1000))
+    if it % 7 == 0: n = int(2 ** rng.uniform(21, 26.3))   # more of the large sort's range
     if kind == "u32" and it % 23 == 0: n = (1 << 26) + int(rng.randint(1, 1 << 22))     # past 256 MiB: pointer stores
-    algo = int(rng.choice([0, 0, 0, 1, -1])); bits = int(rng.choice([8, 8, 8, 4])); tile = int(rng.choice([-1, -1, 0, 1, 2, 5]))
+    algo = int(rng.choice([0, 0, 1, -1, -1, -1])); bits = int(rng.choice([8, 8, 8, 4])); tile = int(rng.choice([-1, -1, 0, 1, 2, 5]))
+    if algo < 0: bits, tile = 8, -1   # what the automatic paths run with
     d.setParam("sort.algo", algo); d.setParam("sort.digit_bits", bits); d.setParam("sort.tile", tile)
-    dist = rng.choice(["uniform", "lowbits", "fewvals", "sortedish"])
+    d.setParam("sort.msd2", int(rng.choice([1, 1, 2])))
+    dist = rng.choice(["uniform", "lowbits", "fewvals", "sortedish", "shifted", "shifted"])
+    shift = int(rng.randint(1, 20))
     if kind in ("u32", "soa", "kv"):
         k = oracle.keys_u32(n, seed=it)
         if dist == "lowbits": k &= np.uint32(0xffff)
         elif dist == "fewvals": k = (k % np.uint32(5)) * np.uint32(0x01010101)
         elif dist == "sortedish": k = np.sort(k)
+        elif dist == "shifted": k >>= np.uint32(shift)
     if kind == "u32":
         b = Buffer(d, n, np.uint32); b.write(k)
         reps = int(rng.randint(1, 4))
@@ -62,6 +68,8 @@ while time.time() < t_end:
     else:
         k64 = oracle.keys_u64(n, seed=it)
         if dist == "lowbits": k64 &= np.uint64(0xffffff)
+        elif dist == "shifted": k64 >>= np.uint64(2 * shift)
+        elif dist == "fewvals": k64 = (k64 % np.uint64(7)) * np.uint64(0x0101010101010101)
         b = Buffer(d, n, np.uint64); b.write(k64); p.radixSort64(d, b, n); out = b.toHost(); b.release()
         assert np.all(out[1:] >= out[:-1]) and checks(out) == checks(k64), (it, kind, n, algo, bits, tile, dist)
     elems += n
