@@ -268,16 +268,26 @@ def main():
 
         # the kernels that move the whole array once (read n*E + write n*E per launch), grouped by KERNEL as rocprofv3 sees
         # them: the two MSD bucket passes of the large keys-only sort are two launches of one kernel
-        groups = {}
+        # algorithmic bytes of one launch (what the step must read and write): a per-digit pass reads and
+        # writes the array; in the large sort the second slab holds the keys' low 16 bits only, so its second pass writes 2 bytes
+        # per key and its finish reads 2
+        large = "msd2_pass1_u32" in prof
+        def alg_bytes(k):
+            if k == "msd2_pass2_u32":
+                return n * (ELEM_BYTES + 2)
+            if k.startswith("segment_sort") and large:
+                return n * (2 + ELEM_BYTES)
+            return 2 * n * ELEM_BYTES
+        groups = {}   # name -> (launches, ms, algorithmic bytes over all launches)
         for k, v in prof.items():
             if k.startswith(("onesweep_", "scatter_", "segment_sort")):
-                groups[k] = (v[0], v[1])
+                groups[k] = (v[0], v[1], v[0] * alg_bytes(k))
             elif k.startswith("msd2_pass"):
-                g = groups.get("msd2_pass_u32", (0, 0.0))
-                groups["msd2_pass_u32"] = (g[0] + v[0], g[1] + v[1])
-        dom_name, (dom_launches, dom_ms) = max(groups.items(), key=lambda kv: kv[1][1])
+                g = groups.get("msd2_pass_u32", (0, 0.0, 0))
+                groups["msd2_pass_u32"] = (g[0] + v[0], g[1] + v[1], g[2] + v[0] * alg_bytes(k))
+        dom_name, (dom_launches, dom_ms, dom_bytes) = max(groups.items(), key=lambda kv: kv[1][1])
         dom_avg_s = dom_ms / dom_launches * 1e-3
-        achieved = 2.0 * n * ELEM_BYTES / dom_avg_s / 1e9
+        achieved = dom_bytes / dom_launches / dom_avg_s / 1e9
         # HBM traffic per launch from PMC counters: collected in separate rocprofv3 --pmc passes of this same
         # command (tools/gpu_session.sh) and stored under profiles/; used only if it is for this kernel and size
         traffic, traffic_src = None, None
@@ -285,7 +295,8 @@ def main():
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
                 t = json.load(open(f))
-                if t.get("profile_name") == dom_name and t.get("keys_per_launch") == n:
+                if (t.get("profile_name") == dom_name and t.get("keys_per_launch") == n
+                        and abs(t.get("algorithmic_bytes_per_launch", 0) - dom_bytes / dom_launches) < 1e-3 * dom_bytes / dom_launches):
                     traffic, traffic_src = t["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
                     break
         except Exception:
@@ -294,9 +305,12 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": dom_name, "launches": dom_launches, "avg_launch_ms": dom_ms / dom_launches,
-            "algorithmic_bytes_per_launch": 2 * n * ELEM_BYTES,
+            "algorithmic_bytes_per_launch": dom_bytes / dom_launches,
             "timing": "hipEvent pair around every launch on the library's stream, second loop over the same K inputs",
         }
+        if dom_name == "msd2_pass_u32":
+            out["roofline"]["note"] = ("two launches of one kernel per sort: pass 1 reads and writes 4 bytes per key, pass 2 reads 4 and "
+                                       "writes 2 (the second slab holds the keys' low 16 bits); bytes and time are averaged over both")
         out["kernels"] = {k: {"launches": v[0], "avg_ms": v[1] / v[0]} for k, v in prof.items()}
         out["probe"] = probe
         out["device"] = info_name
@@ -305,7 +319,7 @@ def main():
         # whole sort on the bytes it really moves: one histogram read (if the path has one) + (read + write) per global pass
         passes = max(1, round(sum(v[0] for v in groups.values()) / K))
         hist_reads = 1 if any(k.startswith(("os_hist_", "count_", "mid_prep")) for k in prof) else 0
-        moved = ELEM_BYTES * (hist_reads + 2 * passes)
+        moved = ELEM_BYTES * hist_reads + sum(v[2] for v in groups.values()) / K / n
         out["whole_sort"] = {"global_passes": passes, "histogram_reads": hist_reads, "bytes_moved_per_key": moved,
                              "achieved_GBps": n * moved / (ev_ms / K * 1e-3) / 1e9,
                              "frac_of_peak": n * moved / (ev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS}

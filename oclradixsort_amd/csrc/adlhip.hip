@@ -664,7 +664,7 @@ int launch_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* s
     });
 }
 
-template <typename E, int K>
+template <typename E, int K, typename S = E>
 int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* seg_start, size_t num_segments, int low_bits,
                              const uint32_t* seg_cnt = nullptr, uint32_t in_stride = 0, const uint32_t* gate = nullptr,
                              const uint32_t* dyn_low_bits = nullptr)
@@ -674,7 +674,7 @@ int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32
     constexpr int WAVES = per_wave <= 6144 ? 8 : per_wave <= 12288 ? 4 : per_wave <= 24576 ? 2 : 1;
     constexpr int STEP = K <= 40 ? 2 : 4;        // row-count bodies: every 2 rows, every 4 for the largest tile
     constexpr int RMIN = K <= 20 ? 2 : K / 2;    // the tiles beyond 20 rows exist for segments that need them
-    auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES, STEP, RMIN>;
+    auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES, STEP, RMIN, S>;
     const size_t lds = (size_t)WAVES * per_wave;
     if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
     const uint32_t grid = (uint32_t)((num_segments + WAVES - 1) / WAVES);
@@ -851,7 +851,7 @@ int mid_sort_keys(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, s
     pa.src = data; pa.dst = slab; pa.cursors = state; pa.cursor_shift = 5; pa.src_count_shift = 0; pa.flag = state + 8192;
     pa.src_counts = nullptr; pa.n = (uint32_t)n; pa.src_stride = 0; pa.tiles_per_bucket = 1; pa.dst_stride = L.stride;
     pa.dst_total = 256u * L.stride; pa.start_bit = 24; pa.zero_me = state + 8194;
-    pa.sample = nullptr; pa.which_digit = 0;
+    pa.sample = nullptr; pa.which_digit = 0; pa.dst16 = 0;
     int rc = launch(d, "mid_bucket_scatter_u32", [&] {
         hipLaunchKernelGGL(ka, dim3(tiles), dim3(256), CA::LDS_BYTES, d->stream, pa);
     });
@@ -973,7 +973,7 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     pa.src = data; pa.dst = slab_a; pa.cursors = cur_a; pa.cursor_shift = 5; pa.src_count_shift = 0; pa.flag = flag;
     pa.src_counts = nullptr; pa.n = (uint32_t)n;
     pa.src_stride = 0; pa.tiles_per_bucket = 1; pa.dst_stride = L.stride_a; pa.dst_total = 256u * L.stride_a; pa.start_bit = KEY_BITS - 8;
-    pa.zero_me = nullptr; pa.sample = sample; pa.which_digit = 1;
+    pa.zero_me = nullptr; pa.sample = sample; pa.which_digit = 1; pa.dst16 = 0;
     const uint32_t tiles_a = (uint32_t)((n + CT::TILE - 1) / CT::TILE);
     rc = launch(d, k32 ? "msd2_pass1_u32" : "msd2_pass1_u64", [&] { hipLaunchKernelGGL(kern, dim3(tiles_a), dim3(512), CT::LDS_BYTES, d->stream, pa); });
     if (rc) return rc;
@@ -983,6 +983,7 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     pb.src_stride = L.stride_a; pb.tiles_per_bucket = L.tiles_per_bucket; pb.dst_stride = L.stride_b;
     pb.dst_total = 65536u * L.stride_b; pb.start_bit = KEY_BITS - 16; pb.zero_me = nullptr;
     pb.sample = sample; pb.which_digit = 2;
+    pb.dst16 = sizeof(E) == 4 ? 1 : 0;   // u32 keys: the second slab holds the low 16 bits only
     rc = launch(d, k32 ? "msd2_pass2_u32" : "msd2_pass2_u64", [&] {
         hipLaunchKernelGGL(kern, dim3(256 * L.tiles_per_bucket), dim3(512), CT::LDS_BYTES, d->stream, pb);
     });
@@ -995,9 +996,10 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     if (rc) return rc;
     // the finish sorts the bits below the second digit (the offsets kernel has published how many), a wave per segment
     const uint32_t* lowb = mode + adlhip::kDynLowBits;
-    if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
-    else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
-    else rc = launch_wave_segment_sort<E, 80>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
+    using S = typename std::conditional<sizeof(E) == 4, uint16_t, E>::type;   // what pass 2 wrote
+    if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
+    else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
+    else rc = launch_wave_segment_sort<E, 80, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
     if (rc) return rc;
     // the safety net: ONE launch that returns at its first instruction unless the mode word is set, in which case its 256
     // resident workgroups sort the untouched input with the cooperative LSD sort (hybrid_kernels.hpp coop_lsd_sort)

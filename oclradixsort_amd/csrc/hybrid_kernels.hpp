@@ -388,20 +388,22 @@ __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, c
 // predicate, only the last R - F are tested per lane.  (With one body for all sizes and `if (row < rows && lane has an item)`
 // around every item the kernel spent ~1200 wave instructions per segment.  Filling up with all-ones pads instead of testing
 // is worse: up to 127 pads bump ONE counter, and same-address LDS atomics serialise.)
-template <typename E, int R, int F>
-__device__ __forceinline__ void wave_sort_rows(const E* __restrict__ src, E* __restrict__ dst, uint32_t m, int lane,
-                                               E* __restrict__ buf, uint32_t* __restrict__ cnt, uint32_t low_bits)
+// S = type of the stored elements: E, or uint16_t -- the large sort keeps only the low 16 bits of u32 keys in its second slab
+// (the bits above are the segment's number) and `hi` puts them back at the final store.
+template <typename E, int R, int F, typename S>
+__device__ __forceinline__ void wave_sort_rows(const S* __restrict__ src, E* __restrict__ dst, uint32_t m, int lane,
+                                               E* __restrict__ buf, uint32_t* __restrict__ cnt, uint32_t low_bits, E hi)
 {
     const int rem = (int)m - lane;   // item j of this lane exists iff j*64 < rem
     E e[R];
 #pragma unroll
     for (int j = 0; j < R; ++j)
-        if (j < F || j * 64 < rem) e[j] = src[j * 64 + lane];
+        if (j < F || j * 64 < rem) e[j] = (E)src[j * 64 + lane];
     const int npass = ((int)low_bits + 7) / 8;   // 8-bit digits at most, as even as possible (u64 keys: up to six passes)
     if (npass == 0) {   // nothing left to sort (the digits above covered every bit that varies): the segment only moves
 #pragma unroll
         for (int j = 0; j < R; ++j)
-            if (j < F || j * 64 < rem) dst[j * 64 + lane] = e[j];
+            if (j < F || j * 64 < rem) dst[j * 64 + lane] = e[j] | hi;
         return;
     }
     int sb = 0;
@@ -440,27 +442,27 @@ __device__ __forceinline__ void wave_sort_rows(const E* __restrict__ src, E* __r
     }
 #pragma unroll
     for (int j = 0; j < R; ++j)
-        if (j < F || j * 64 < rem) dst[j * 64 + lane] = buf[j * 64 + lane];
+        if (j < F || j * 64 < rem) dst[j * 64 + lane] = buf[j * 64 + lane] | hi;
 }
 
 // rows -> the smallest body that holds them: bodies for RMIN (any number of rows up to RMIN: every row tested), RMIN + STEP,
 // ..., K rows.  A kernel for large tiles (K = 40, 80: segments of the large sort beyond 64 Mi keys) starts at K / 2 -- its
 // segments are that large -- and steps by 4 to keep the code size in bounds.
-template <typename E, int R, int K, int STEP, bool FIRST>
-__device__ __forceinline__ void wave_sort_dispatch(int rows, const E* __restrict__ src, E* __restrict__ dst, uint32_t m, int lane,
-                                                   E* __restrict__ buf, uint32_t* __restrict__ cnt, uint32_t low_bits)
+template <typename E, int R, int K, int STEP, bool FIRST, typename S>
+__device__ __forceinline__ void wave_sort_dispatch(int rows, const S* __restrict__ src, E* __restrict__ dst, uint32_t m, int lane,
+                                                   E* __restrict__ buf, uint32_t* __restrict__ cnt, uint32_t low_bits, E hi)
 {
     constexpr int RR = R < K ? R : K;
     constexpr int F = FIRST ? 0 : RR - STEP;
     if constexpr (R >= K) {
-        wave_sort_rows<E, RR, F>(src, dst, m, lane, buf, cnt, low_bits);
+        wave_sort_rows<E, RR, F, S>(src, dst, m, lane, buf, cnt, low_bits, hi);
     } else {
-        if (rows <= R) wave_sort_rows<E, RR, F>(src, dst, m, lane, buf, cnt, low_bits);
-        else wave_sort_dispatch<E, R + STEP, K, STEP, false>(rows, src, dst, m, lane, buf, cnt, low_bits);
+        if (rows <= R) wave_sort_rows<E, RR, F, S>(src, dst, m, lane, buf, cnt, low_bits, hi);
+        else wave_sort_dispatch<E, R + STEP, K, STEP, false, S>(rows, src, dst, m, lane, buf, cnt, low_bits, hi);
     }
 }
 
-template <typename E, int K, int WAVES, int STEP, int RMIN>
+template <typename E, int K, int WAVES, int STEP, int RMIN, typename S>
 __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* in, E* out, const uint32_t* __restrict__ seg_start,
                                                                         uint32_t num_segments, uint32_t low_bits, uint32_t* fault,
                                                                         const uint32_t* __restrict__ seg_cnt, uint32_t in_stride,
@@ -486,8 +488,15 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
         if (lane == 0) atomicOr(fault + 1, 0x40000u);
         return;
     }
-    const E* src = in + (seg_cnt ? (size_t)seg * in_stride : (size_t)begin);
-    wave_sort_dispatch<E, RMIN, K, STEP, true>((int)((m + 63u) >> 6), src, out + begin, m, lane, buf, cnt, low_bits);
+    if constexpr (sizeof(S) == sizeof(E)) {
+        const E* src = in + (seg_cnt ? (size_t)seg * in_stride : (size_t)begin);
+        wave_sort_dispatch<E, RMIN, K, STEP, true, E>((int)((m + 63u) >> 6), src, out + begin, m, lane, buf, cnt, low_bits, E(0));
+    } else {
+        // slab form with 16-bit elements: the key's bits above low_bits are (sampled prefix, segment number)
+        const S* src = reinterpret_cast<const S*>(in) + (size_t)seg * in_stride;
+        const E hi = (E)(((dyn_low_bits[1] << 16) | seg) << low_bits);
+        wave_sort_dispatch<E, RMIN, K, STEP, true, S>((int)((m + 63u) >> 6), src, out + begin, m, lane, buf, cnt, low_bits, hi);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -522,6 +531,9 @@ struct BucketPass {
     uint32_t* zero_me;            // one word the first workgroup clears (the safety net's barrier counter), or nullptr
     const uint32_t* sample;       // nullptr, or the four sample words (msd2_placement): start_bit = top - 8 * which_digit
     int which_digit;              // 1 = first digit, 2 = second
+    int dst16;                    // the destination slabs hold uint16_t: only the key's low 16 bits are written (the second pass of
+                                  // u32 keys: the bits above are the segment's number -- 128 MiB less to write and to read back
+                                  // at 64 Mi keys)
 };
 
 // Digit placement of the large keys-only sort, chosen on the device from a sample of the keys: keys that do not use their top
@@ -714,9 +726,24 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
         go.y = (d0 + 1u) * a.dst_stride + at4.y - toff4.y;
         go.z = (d0 + 2u) * a.dst_stride + at4.z - toff4.z;
         go.w = (d0 + 3u) * a.dst_stride + at4.w - toff4.w;
-        *reinterpret_cast<u32x4*>(s_goff + 4 * lane) = scaled ? go * (uint32_t)IO::kStoreScale : go;
+        *reinterpret_cast<u32x4*>(s_goff + 4 * lane) = (scaled && !a.dst16) ? go * (uint32_t)IO::kStoreScale : go;
     }
     __syncthreads();
+    if (a.dst16) {
+        // one 2-byte store per key (two tile positions per lane packed into one 4-byte store where they share a run was no
+        // faster: 119.9 vs 120.8 us at 64 Mi keys)
+        uint16_t* __restrict__ d16 = reinterpret_cast<uint16_t*>(a.dst);
+#pragma unroll 8
+        for (int i = 0; i < K; ++i) {
+            const uint32_t pos = (uint32_t)(tid + i * NT);
+            if (pos < valid) {
+                const E v = s_elems[pos];
+                const uint32_t g = s_goff[digit_of<8>(v, start_bit)] + pos;
+                if (g < a.dst_total) d16[g] = (uint16_t)v;
+            }
+        }
+        return;
+    }
     write_out_tile<IO, 8, NT, K, ADLHIP_WRITE_UNROLL>(io, s_elems, s_goff, valid, a.dst_total, start_bit, scaled);
 }
 
@@ -759,6 +786,7 @@ __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, 
             seg_off[65536] = n;
             if (sample) {   // the finish sorts the bits below the second digit; the sample words go back to or = 0 / and = ~0
                 mode[kDynLowBits] = (uint32_t)(msd2_placement(sample).top - 16);
+                mode[kDynLowBits + 1] = (uint32_t)msd2_placement(sample).prefix;   // for the finish of a 16-bit second slab
                 __hip_atomic_store(sample + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(sample + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(sample + 2, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -35,7 +35,9 @@ json.dump({
                        "guide calibrates that for 16-B-per-lane loads, this kernel loads one dword per lane: 2 x FETCH_SIZE here equals "
                        "the %.1f MB of keys (+ ~4 MB of status rows in the one-sweep pass) the kernel is known to read, so the factor holds for it; both counters "
                        "sit on the memory side of L2 (fabric requests), Infinity-Cache hits included" % (n * 4 / 1e6),
-    "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": 2 * n * 4,
+    "traffic_bytes_per_launch": traffic,
+    # the MSD bucket pass runs twice per sort: 4 + 4 bytes per key, then 4 + 2 (16-bit second slab): the average, as bench.py prices it
+    "algorithmic_bytes_per_launch": (2 * n * 4 + n * 6) // 2 if profile_name == "msd2_pass_u32" else 2 * n * 4,
     "how": "two separate runs of `rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py --steps 5 --warmup 1 "
            "--no-cpu-baseline --no-verify` (tools/gpu_session.sh)",
 }, open(out, "w"), indent=1)
