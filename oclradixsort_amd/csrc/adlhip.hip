@@ -903,7 +903,7 @@ Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
     L.off_coop = align_up(L.off_off + 65537 * 4, 256);                       // safety net: table [256][256] + 256 totals
     L.off_slab_a = align_up(L.off_coop + (size_t)256 * 256 * 4 + 1024, 256);
     L.off_slab_b = align_up(L.off_slab_a + (size_t)256 * L.stride_a * elem_bytes, 256);
-    L.total = L.off_slab_b + (size_t)65536 * L.stride_b * elem_bytes;
+    L.total = L.off_slab_b + (size_t)65536 * L.stride_b * (elem_bytes == 4 ? 2 : elem_bytes);   // u32 keys: 16-bit second slab
     return L;
 }
 
