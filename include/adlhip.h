@@ -293,7 +293,7 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      LDS (six moves of every element instead of nine); where the two digits sit is chosen on the
  *                      device from a sample of the keys.  Keys only: runs are placed with atomic cursors (equal
  *                      keys are indistinguishable); pairs: by look-back, stably.  Keys that do not fit the slabs
- *                      are detected on the device and sorted by a cooperative LSD sort in one further launch
+ *                      are detected on the device and sorted by a cooperative LSD sort inside the same launches
  *                      (correct, slower); asynchronous hints then keep such a handle on the per-digit passes
  *                      (speed only).  2 forces the path from 1 Mi elements (tests)
  *   "profile"          0/1: bracket every kernel launch with hipEvents (Device::toggleProfiling,

@@ -966,7 +966,7 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     // where the two digits sit is chosen on the device from a sample of the keys (hybrid_kernels.hpp msd2_sample_kernel)
     int rc = launch(d, "msd2_sample", [&] {
         hipLaunchKernelGGL(adlhip::msd2_sample_kernel<E>, dim3(adlhip::kSampleWGs), dim3(64), 0, d->stream, (const E*)data, (uint32_t)n,
-                           sample);
+                           sample, flag + 2);
     });
     if (rc) return rc;
     adlhip::BucketPass<E> pa;   // pass 1: the input, first digit -> 256 bucket slabs
@@ -988,10 +988,14 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
         hipLaunchKernelGGL(kern, dim3(256 * L.tiles_per_bucket), dim3(512), CT::LDS_BYTES, d->stream, pb);
     });
     if (rc) return rc;
+    // segment sizes and offsets -- and, when a run did not fit its slab, the safety net: the same 256 resident workgroups sort
+    // the untouched input with the cooperative LSD sort (hybrid_kernels.hpp coop_lsd_sort); the finish then returns at once
     uint32_t* bar = done + 1;
+    uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
+    using CC = adlhip::TileCfg<E, 8, 256, 16>;
     rc = launch(d, "msd2_offsets", [&] {
-        hipLaunchKernelGGL(adlhip::msd2_offsets_kernel, dim3(256), dim3(256), 0, d->stream, cur_a, cur_b, flag, done, bar, seg_cnt, seg_off,
-                           mode, d->h_fault + 11, (uint32_t)n, sample);
+        hipLaunchKernelGGL(adlhip::msd2_offsets_kernel<E>, dim3(256), dim3(256), CC::LDS_BYTES, d->stream, cur_a, cur_b, flag, done, bar,
+                           seg_cnt, seg_off, mode, d->h_fault + 11, (uint32_t)n, sample, data, tmp, ctable, d->d_fault, KEY_BITS);
     });
     if (rc) return rc;
     // the finish sorts the bits below the second digit (the offsets kernel has published how many), a wave per segment
@@ -1001,15 +1005,7 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
     else rc = launch_wave_segment_sort<E, 80, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
     if (rc) return rc;
-    // the safety net: ONE launch that returns at its first instruction unless the mode word is set, in which case its 256
-    // resident workgroups sort the untouched input with the cooperative LSD sort (hybrid_kernels.hpp coop_lsd_sort)
-    auto coop = adlhip::coop_lsd_sort_kernel<E, 512, K>;
-    if (ensure_lds(coop, CT::LDS_BYTES)) return ADLHIP_FAILURE;
-    uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
-    return launch(d, k32 ? "msd2_coop_lsd_u32" : "msd2_coop_lsd_u64", [&] {
-        hipLaunchKernelGGL(coop, dim3(256), dim3(512), CT::LDS_BYTES, d->stream, data, tmp, (uint32_t)n, ctable, ctable + 256 * 256, bar,
-                           (const uint32_t*)mode, d->d_fault, KEY_BITS);
-    });
+    return rc;
 }
 
 // ---- the same for {key, value} pairs, STABLE: look-back instead of cursors (hybrid_kernels.hpp msd_lookback_scatter_kernel) --
@@ -1115,7 +1111,7 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     HIPCHK(hipMemsetAsync(status_a, 0, (L.off_status_b - L.off_status_a) + L.status_bytes_b, d->stream));
     int rc = launch(d, "msd2s_prep", [&] {
         hipLaunchKernelGGL(adlhip::msd2s_prep_kernel<E>, dim3(1), dim3(1024), 0, d->stream, (const E*)data, (uint32_t)n, place, tickets,
-                           L.ticket_words);
+                           L.ticket_words, bar);
     });
     if (rc) return rc;
     adlhip::LookbackPass<E> pa;
@@ -1136,10 +1132,13 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
         hipLaunchKernelGGL(kern, dim3(256 * L.rows_b), dim3(512), CT::LDS_BYTES, d->stream, pb);
     });
     if (rc) return rc;
+    uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
+    using CC = adlhip::TileCfg<E, 8, 256, 16>;   // the safety net's tile (it runs in the offsets kernel when a run did not fit)
     rc = launch(d, "msd2s_offsets", [&] {
-        hipLaunchKernelGGL(adlhip::msd2s_offsets_kernel<CT::TILE>, dim3(256), dim3(256), 0, d->stream, (const uint32_t*)status_a, L.rows_a,
-                           L.slice, L.pieces, (const uint32_t*)status_b, L.rows_b, L.stride_a, flag, done, bar, seg_cnt, seg_off, mode,
-                           d->h_fault + 11, (uint32_t)n, (const adlhip::StablePlace*)place);
+        hipLaunchKernelGGL((adlhip::msd2s_offsets_kernel<E, CT::TILE>), dim3(256), dim3(256), CC::LDS_BYTES, d->stream,
+                           (const uint32_t*)status_a, L.rows_a, L.slice, L.pieces, (const uint32_t*)status_b, L.rows_b, L.stride_a, flag,
+                           done, bar, seg_cnt, seg_off, mode, d->h_fault + 11, (uint32_t)n, (const adlhip::StablePlace*)place, data, tmp,
+                           ctable, d->d_fault);
     });
     if (rc) return rc;
     const uint32_t* lowb = mode + adlhip::kDynLowBits;
@@ -1147,13 +1146,7 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
     else rc = launch_wave_segment_sort<E, 80>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
     if (rc) return rc;
-    auto coop = adlhip::coop_lsd_sort_kernel<E, 512, 16>;
-    if (ensure_lds(coop, CT::LDS_BYTES)) return ADLHIP_FAILURE;
-    uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
-    return launch(d, "msd2s_coop_lsd_kv32", [&] {
-        hipLaunchKernelGGL(coop, dim3(256), dim3(512), CT::LDS_BYTES, d->stream, data, tmp, (uint32_t)n, ctable, ctable + 256 * 256, bar,
-                           (const uint32_t*)mode, d->d_fault, 32);
-    });
+    return rc;
 }
 
 size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)

@@ -129,16 +129,6 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
     }
 }
 
-template <typename E, int NT, int K>
-__global__ __launch_bounds__(NT) void coop_lsd_sort_kernel(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table,
-                                                           uint32_t* __restrict__ totals, uint32_t* bar,
-                                                           const uint32_t* __restrict__ gate, uint32_t* fault, int key_bits)
-{
-    if (*gate == 0u) return;   // the large keys-only sort fitted its slabs: nothing to do
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    coop_lsd_sort<E, NT, K>(data, tmp, n, table, totals, bar, fault, smem, key_bits);
-}
-
 // ------------------------------------------------------------------------------------------
 // C: finish segments in LDS.  A workgroup takes segments blockIdx.x, blockIdx.x + gridDim.x, ...  The segment
 // [seg_start[s], seg_start[s+1]) of `in` is loaded once, sorted on its low `low_bits` bits with up to three stable
@@ -563,8 +553,10 @@ constexpr int kSampleWGs = 16;
 enum { kDynMode = 0, kDynLowBits = 4 };   // words of the sort's mode block (work buffer): [4] = bits the finish sorts
 
 template <typename E>
-__global__ __launch_bounds__(64) void msd2_sample_kernel(const E* __restrict__ src, uint32_t n, uint32_t* sample)
+__global__ __launch_bounds__(64) void msd2_sample_kernel(const E* __restrict__ src, uint32_t n, uint32_t* sample, uint32_t* bar)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0)   // the safety net's grid-barrier counter (used, if at all, in the offsets kernel)
+        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long k = (unsigned long long)(blockIdx.x * 64u + threadIdx.x);
     const unsigned long long v = (unsigned long long)src[(size_t)(k * (unsigned long long)n / (unsigned long long)(kSampleWGs * 64))];
     unsigned long long o = v, a = v;
@@ -753,19 +745,26 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
 // 16 bits).  No histogram kernel, no look-back, 6 sweeps of the data instead of 9.  msd2_offsets_kernel sits between the
 // second pass and the finish: workgroup b turns bucket b's 256 cursors into output offsets (bucket base = scan of the first
 // pass's cursors), saves the counts for the finish, clears the cursors for the next sort (they belong to the device handle),
-// and the last workgroup publishes the mode word: 0 = every run fitted its slab; else 1 -- the finish returns at once and
-// coop_lsd_sort_kernel, one launch that is always enqueued behind it and returns at its first instruction while the word is 0,
-// sorts the untouched input (slowly: it is the safety net; the host's hint keeps such inputs off this path).
+// and the last workgroup publishes the mode word: 0 = every run fitted its slab; else 1 -- the finish returns at once, and the
+// workgroups of THIS kernel go on to sort the untouched input with the cooperative LSD sort (slowly: it is the safety net; the
+// host's hint keeps such inputs off this path).
 // ------------------------------------------------------------------------------------------
+// The safety net lives in this kernel too: its 256 workgroups are all resident, so when the overflow flag is set they go on to
+// sort the untouched input with the cooperative LSD sort (a launch of its own that returns at once cost 5-6 us per sort).
+template <typename E>
 __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, uint32_t* cursors_b, uint32_t* flag, uint32_t* done,
                                                            uint32_t* bar, uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_off,
                                                            uint32_t* __restrict__ mode, uint32_t* host_mode, uint32_t n,
-                                                           uint32_t* sample)
+                                                           uint32_t* sample, E* data, E* tmp, uint32_t* __restrict__ ctable,
+                                                           uint32_t* fault, int key_bits)
 {
     __shared__ uint32_t s_wsum[256 / 64 + 1];
     __shared__ uint32_t s_misc[4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the safety net's tile (TileCfg<E, 8, 256, 16>)
     const int t = (int)threadIdx.x;
     const uint32_t b = blockIdx.x;
+    // final since pass 2 has completed; every workgroup reads it BEFORE it counts itself done, the last one done clears it
+    const uint32_t overflow = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t ca = __hip_atomic_load(cursors_a + 32 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one line per cursor
     const uint32_t exa = block_excl_scan_u32<256>(ca, s_wsum, nullptr);
     if (t == (int)b) s_misc[0] = exa;
@@ -781,8 +780,7 @@ __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, 
     if (s_misc[1] == gridDim.x - 1u) {
         __hip_atomic_store(cursors_a + 32 * t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == 0) {
-            const uint32_t f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *mode = f ? 1u : 0u;
+            *mode = overflow ? 1u : 0u;   // the finish returns at once when it is set
             seg_off[65536] = n;
             if (sample) {   // the finish sorts the bits below the second digit; the sample words go back to or = 0 / and = ~0
                 mode[kDynLowBits] = (uint32_t)(msd2_placement(sample).top - 16);
@@ -794,9 +792,12 @@ __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, 
             }
             __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // grid-barrier counter of the safety net
-            __hip_atomic_store(host_mode, 1u + (f ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_mode, 1u + (overflow ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    }
+    if (overflow) {   // `bar` is zero here: msd2_sample_kernel, the first launch of every sort, clears it
+        __syncthreads();
+        coop_lsd_sort<E, 256, 16>(data, tmp, n, ctable, ctable + 256 * 256, bar, fault, smem, key_bits);
     }
 }
 
@@ -827,10 +828,11 @@ struct StablePlace {   // written by msd2s_prep_kernel
 // one workgroup: sample 1024 keys -> digit placement; clear the tickets of both passes
 template <typename E>
 __global__ __launch_bounds__(1024) void msd2s_prep_kernel(const E* __restrict__ src, uint32_t n, StablePlace* __restrict__ place,
-                                                           uint32_t* __restrict__ tickets, uint32_t ticket_words)
+                                                           uint32_t* __restrict__ tickets, uint32_t ticket_words, uint32_t* bar)
 {
     __shared__ uint32_t s_or[16], s_and[16];
     const int tid = (int)threadIdx.x;
+    if (tid == 0) __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the safety net's grid-barrier counter
     for (uint32_t i = (uint32_t)tid; i < ticket_words; i += 1024u) tickets[i] = 0u;
     const uint32_t v = (uint32_t)src[(size_t)((unsigned long long)tid * n / 1024ull)];   // the key is the low dword
     uint32_t o = v, a = v;
@@ -1104,19 +1106,24 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
 
 // Between pass B and the finish: workgroup b turns bucket b's final counts (the last status row of chain b) into the
 // segments' sizes and output offsets; the last workgroup publishes the mode word and the host's hint.
-template <int TILE>
+// As in the keys-only form, the safety net runs in this kernel when the overflow flag is set.
+template <typename E, int TILE>
 __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __restrict__ status_a, uint32_t rows_per_chain_a, uint32_t slice,
                                                             uint32_t pieces,
                                                             const uint32_t* __restrict__ status_b, uint32_t rows_per_chain_b,
                                                             uint32_t src_stride, uint32_t* flag, uint32_t* done, uint32_t* bar,
                                                             uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_off,
                                                             uint32_t* __restrict__ mode, uint32_t* host_mode, uint32_t n,
-                                                            const StablePlace* __restrict__ place)
+                                                            const StablePlace* __restrict__ place, E* data, E* tmp,
+                                                            uint32_t* __restrict__ ctable, uint32_t* fault)
 {
     __shared__ uint32_t s_wsum[256 / 64 + 1];
     __shared__ uint32_t s_misc[4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the safety net's tile (TileCfg<E, 8, 256, 16>)
     const int t = (int)threadIdx.x;
     const uint32_t b = blockIdx.x;
+    // final since pass B has completed; read by every workgroup BEFORE it counts itself done, cleared by the last one done
+    const uint32_t overflow = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // thread t: size of bucket t = sum of its 16 sub-slabs; and the tiles pass B made of it
     uint32_t size_t_ = 0u, tiles_t = 0u;
     for (uint32_t c = 0; c < pieces; ++c) {
@@ -1143,14 +1150,16 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
     if (t == 0) s_misc[2] = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_misc[2] == gridDim.x - 1u && t == 0) {
-        const uint32_t f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *mode = f ? 1u : 0u;
+        *mode = overflow ? 1u : 0u;
         mode[kDynLowBits] = place->low_bits;
         seg_off[65536] = n;
         __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(host_mode, 1u + (f ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_mode, 1u + (overflow ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (overflow) {   // `bar` is zero here: msd2s_prep_kernel, the first launch of every sort, clears it
+        __syncthreads();
+        coop_lsd_sort<E, 256, 16>(data, tmp, n, ctable, ctable + 256 * 256, bar, fault, smem, 32);
     }
 }
 
