@@ -85,9 +85,11 @@ struct adlhip_device {
     int mid_skip = 0;         // eligible sorts still to be sent down the per-digit passes after a skewed input (see mid_eligible)
     int mid2_skip = 0;        // keys-only sorts still to take the three-launch form after a slab overflow (see mid_sort_keys)
     int mid_backoff = 32, mid2_backoff = 64;
-    int msd2_path = 1;        // 4 Mi < n <= 64 Mi u32 keys: two MSD passes with bucket cursors + LDS finish (msd2_sort)
-    int msd2_skip = 0, msd2_backoff = 32;
-    uint32_t* d_msd2 = nullptr;   // msd2_sort's cursors (256 padded to a line each + 65536) + flag + done counter, allocated on first use   // how many sorts the next fallback / overflow skips (x8 each time, reset by a success)
+    int msd2_path = 1;        // "sort.msd2": the large sort (msd2_sort for keys, msd2s_sort for pairs); 2 = forced (tests)
+    int msd2_skip = 0, msd2_backoff = 32;   // sorts the next overflow report keeps off the large sort (x8 each time, reset by a success)
+    uint32_t* d_msd2 = nullptr;   // the large sort's handle-owned words, allocated on first use and zero between sorts: cursors of
+                                  // pass 1 (256, one 128-byte line each) and pass 2 (65536), overflow flag, done counter, the safety
+                                  // net's barrier counter, the four sample words
     // profiling
     std::vector<PendingProf> pending;
     std::vector<hipEvent_t> event_pool;

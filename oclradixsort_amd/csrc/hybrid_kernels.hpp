@@ -1,5 +1,5 @@
-// hybrid_kernels.hpp -- MSD pass + LDS-resident finish: the segment sort primitive (adlhip_segment_sort) and the
-// mid-size sort built on it.
+// hybrid_kernels.hpp -- MSD passes + LDS-resident finish: the segment sort primitive (adlhip_segment_sort), the mid-size
+// sort (16 Ki .. 2 Mi keys) and the large sort (2 Mi .. 280 Mi keys, u64 keys, pairs) built on it.
 //
 // The LSD sort of Pprims::radixSort (Tahoe/ParallelPrimitives/Pprims.cpp:304-406) moves every element through
 // global memory once per digit and costs one to three dependent kernel launches per digit.  Between 16 Ki and
@@ -8,9 +8,10 @@
 // LDS need three launches in all.  The result is the array any stable sort produces (total order + stability =>
 // unique output), so parity with the reference's CPU sort (Tahoe/Algorithm/Sort/RadixSort.cpp:10-104) is unaffected.
 //
-// Measured and NOT built on this (profiles/r2_segment_sort_*.txt): the same structure for 64 Mi keys (two MSD passes
-// of 7 bits + finish on 18 bits).  The finishing kernel is bound by its LDS traffic and barriers (250-320 us for
-// 64 Mi keys, workgroup- or wave-per-segment alike), more than the one global pass it would save.
+// The same idea at full size is the large sort further down: two MSD passes of 8 bits into slabs + a finish on the 16 bits
+// below.  (A first attempt -- stable passes of 7 bits with histograms, finish on 18 bits, profiles/r2_segment_sort_*.txt --
+// lost to the per-digit passes: 250-320 us for the finish alone.  What made it pay: no histogram and no look-back at all
+// for keys (atomic cursors into slabs), segments small enough for ONE WAVE each, and a finish without per-item predicates.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -740,9 +741,10 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
 }
 
 // ------------------------------------------------------------------------------------------
-// Large keys-only sort ("sort.msd2", 4 Mi < n <= 64 Mi u32 keys): TWO unstable MSD passes with bucket cursors (top byte, then
-// second byte inside every bucket: 65536 segments of n / 65536 keys) and ONE LDS finish (wave_segment_sort_kernel on the low
-// 16 bits).  No histogram kernel, no look-back, 6 sweeps of the data instead of 9.  msd2_offsets_kernel sits between the
+// Large keys-only sort ("sort.msd2", 2 Mi < n <= 280 Mi u32 keys, u64 keys likewise): TWO unstable MSD passes with bucket
+// cursors (first digit, then second digit inside every bucket: 65536 segments of n / 65536 keys; where the digits sit is chosen
+// from a sample of the keys, msd2_placement) and ONE LDS finish (wave_segment_sort_kernel on the bits below).  No histogram
+// kernel, no look-back, every key moved 6 times instead of 9 (u32 keys: the second slab holds their low 16 bits only).  msd2_offsets_kernel sits between the
 // second pass and the finish: workgroup b turns bucket b's 256 cursors into output offsets (bucket base = scan of the first
 // pass's cursors), saves the counts for the finish, clears the cursors for the next sort (they belong to the device handle),
 // and the last workgroup publishes the mode word: 0 = every run fitted its slab; else 1 -- the finish returns at once, and the

@@ -1120,8 +1120,8 @@ def test_mid_size_sort_forms_on_friendly_and_skewed_keys(dev, form):
 
 def test_large_keys_only_sort_two_msd_passes_and_lds_finish(dev):
     """"sort.msd2" forced on: two unstable MSD passes with bucket cursors + the wave-per-segment LDS finish, for sizes across its
-    range, on keys that fit its slabs and on keys that do not (the mode word then lets the cooperative LSD sort, one launch that is
-    always enqueued behind it, sort the untouched input).  Bit-exact against the oracle either way."""
+    range, on keys that fit its slabs and on keys that do not (the offsets kernel's workgroups then sort the untouched input with the
+    cooperative LSD sort and the finish returns at once).  Bit-exact against the oracle either way."""
     set_algo(dev, (-1, 8, -1))
     dev.setParam("sort.msd2", 2)
     p = Pprims()
