@@ -666,23 +666,23 @@ int launch_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* s
     });
 }
 
-template <typename E, int K, typename S = E>
+template <typename E, int K, typename S = E, bool SOA = false>
 int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* seg_start, size_t num_segments, int low_bits,
                              const uint32_t* seg_cnt = nullptr, uint32_t in_stride = 0, const uint32_t* gate = nullptr,
-                             const uint32_t* dyn_low_bits = nullptr)
+                             const uint32_t* dyn_low_bits = nullptr, uint32_t* out_vals = nullptr)
 {
     // a wave's LDS: its tile + 256 counters; waves per workgroup so that a workgroup takes at most ~48 KiB (three per CU)
     constexpr size_t per_wave = sizeof(E) * 64 * K + 256 * 4;
     constexpr int WAVES = per_wave <= 6144 ? 8 : per_wave <= 12288 ? 4 : per_wave <= 24576 ? 2 : 1;
     constexpr int STEP = K <= 40 ? 2 : 4;        // row-count bodies: every 2 rows, every 4 for the largest tile
     constexpr int RMIN = K <= 20 ? 2 : K / 2;    // the tiles beyond 20 rows exist for segments that need them
-    auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES, STEP, RMIN, S>;
+    auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES, STEP, RMIN, S, SOA>;
     const size_t lds = (size_t)WAVES * per_wave;
     if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
     const uint32_t grid = (uint32_t)((num_segments + WAVES - 1) / WAVES);
     return launch(d, sizeof(E) == 4 ? "segment_sort_wave_u32" : "segment_sort_wave_e64", [&] {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, d->stream, in, out, seg_start, (uint32_t)num_segments,
-                           (uint32_t)low_bits, d->d_fault, seg_cnt, in_stride, gate, dyn_low_bits);
+                           (uint32_t)low_bits, d->d_fault, seg_cnt, in_stride, gate, dyn_low_bits, out_vals);
     });
 }
 
@@ -1082,7 +1082,10 @@ bool msd2s_eligible(const adlhip_device* d, size_t elem_bytes, size_t n, int sor
     return n > (d->msd2_path == 2 ? kMsd2Min : kMsd2sAutoMin) && n <= kMsd2sMax;
 }
 
-int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size_t n)
+// AoS pairs: data / tmp.  SoA pairs (soa_keys != nullptr): the input and output are the two u32 arrays; data / tmp are unused
+// (the safety net packs the input into the first slab area and sorts it there against the second).
+int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size_t n, uint32_t* soa_keys = nullptr,
+               uint32_t* soa_vals = nullptr)
 {
     typedef uint64_t E;
     if (!d->d_msd2) {
@@ -1112,8 +1115,12 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     // status rows of both passes: zero (one memset; the rows are contiguous)
     HIPCHK(hipMemsetAsync(status_a, 0, (L.off_status_b - L.off_status_a) + L.status_bytes_b, d->stream));
     int rc = launch(d, "msd2s_prep", [&] {
-        hipLaunchKernelGGL(adlhip::msd2s_prep_kernel<E>, dim3(1), dim3(1024), 0, d->stream, (const E*)data, (uint32_t)n, place, tickets,
-                           L.ticket_words, bar);
+        if (soa_keys)
+            hipLaunchKernelGGL(adlhip::msd2s_prep_kernel<uint32_t>, dim3(1), dim3(1024), 0, d->stream, (const uint32_t*)soa_keys,
+                               (uint32_t)n, place, tickets, L.ticket_words, bar);
+        else
+            hipLaunchKernelGGL(adlhip::msd2s_prep_kernel<E>, dim3(1), dim3(1024), 0, d->stream, (const E*)data, (uint32_t)n, place, tickets,
+                               L.ticket_words, bar);
     });
     if (rc) return rc;
     adlhip::LookbackPass<E> pa;
@@ -1121,7 +1128,8 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     pa.flag = flag; pa.fault = d->d_fault; pa.place = place; pa.which_digit = 1; pa.n = (uint32_t)n; pa.chains = L.pieces; pa.pieces = L.pieces;
     pa.rows_per_chain = L.rows_a; pa.slice = L.slice; pa.src_stride = 0; pa.status_a = nullptr; pa.rows_per_chain_a = 0;
     pa.dst_stride = L.stride_a; pa.dst_total = 256u * L.pieces * L.stride_a;
-    rc = launch(d, "msd2s_pass1_kv32", [&] {
+    pa.soa_keys = soa_keys; pa.soa_vals = soa_vals;
+    rc = launch(d, soa_keys ? "msd2s_pass1_soa" : "msd2s_pass1_kv32", [&] {
         hipLaunchKernelGGL(kern, dim3(L.pieces * L.rows_a), dim3(512), CT::LDS_BYTES, d->stream, pa);
     });
     if (rc) return rc;
@@ -1130,7 +1138,8 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     pb.tickets = tickets + 32 * adlhip::kTicketStride; pb.which_digit = 2; pb.chains = 256; pb.rows_per_chain = L.rows_b;
     pb.src_stride = L.stride_a; pb.status_a = status_a; pb.rows_per_chain_a = L.rows_a; pb.dst_stride = L.stride_b;
     pb.dst_total = 65536u * L.stride_b;
-    rc = launch(d, "msd2s_pass2_kv32", [&] {
+    pb.soa_keys = nullptr; pb.soa_vals = nullptr;
+    rc = launch(d, soa_keys ? "msd2s_pass2_soa" : "msd2s_pass2_kv32", [&] {
         hipLaunchKernelGGL(kern, dim3(256 * L.rows_b), dim3(512), CT::LDS_BYTES, d->stream, pb);
     });
     if (rc) return rc;
@@ -1139,15 +1148,21 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     rc = launch(d, "msd2s_offsets", [&] {
         hipLaunchKernelGGL((adlhip::msd2s_offsets_kernel<E, CT::TILE>), dim3(256), dim3(256), CC::LDS_BYTES, d->stream,
                            (const uint32_t*)status_a, L.rows_a, L.slice, L.pieces, (const uint32_t*)status_b, L.rows_b, L.stride_a, flag,
-                           done, bar, seg_cnt, seg_off, mode, d->h_fault + 11, (uint32_t)n, (const adlhip::StablePlace*)place, data, tmp,
-                           ctable, d->d_fault);
+                           done, bar, seg_cnt, seg_off, mode, d->h_fault + 11, (uint32_t)n, (const adlhip::StablePlace*)place,
+                           soa_keys ? slab_a : data, soa_keys ? slab_b : tmp, ctable, d->d_fault, soa_keys, soa_vals);
     });
     if (rc) return rc;
     const uint32_t* lowb = mode + adlhip::kDynLowBits;
+    if (soa_keys) {   // the finish writes keys and values to their own arrays
+        E* ko = reinterpret_cast<E*>(soa_keys);
+        if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
+        else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
+        else rc = launch_wave_segment_sort<E, 80, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
+        return rc;
+    }
     if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
     else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
     else rc = launch_wave_segment_sort<E, 80>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
-    if (rc) return rc;
     return rc;
 }
 
@@ -1162,7 +1177,7 @@ size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)
     size_t e = 0;   // large keys-only sort: slabs behind the one-sweep layout (monotone in n up to its limit)
     if (elem_kind == ADLHIP_ELEM_U32 && n > kMsd2Min) e = msd2_layout(std::min(n, kMsd2MaxU32), 4).total;
     if (elem_kind == ADLHIP_ELEM_U64 && n > kMsd2Min) e = msd2_layout(std::min(n, kMsd2MaxU64), 8).total;
-    if (elem_kind == ADLHIP_ELEM_KV32 && n > kMsd2Min) e = msd2s_layout(std::min(n, kMsd2sMax)).total;
+    if ((elem_kind == ADLHIP_ELEM_KV32 || elem_kind == ADLHIP_ELEM_SOA32) && n > kMsd2Min) e = msd2s_layout(std::min(n, kMsd2sMax)).total;
     return std::max(std::max(a, b), std::max(c, e));
 }
 
@@ -1706,6 +1721,7 @@ int adlhip_radix_sort_soa32(adlhip_device* d, uint32_t* keys, uint32_t* vals, ui
     if (!vals || !tmp_vals) return fail("null value buffer passed to radix sort");
     if ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(tmp_vals)) & 15u)
         return fail("sort buffers must be 16-byte aligned");
+    if (msd2s_eligible(d, 8, n, sort_bits, 32) && msd2_wanted(d)) return msd2s_sort(d, nullptr, nullptr, work, n, keys, vals);
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
     return run_sort<SoaBuf>(d, SoaBuf{keys, vals}, SoaBuf{tmp_keys, tmp_vals}, work, n, plan);
 }

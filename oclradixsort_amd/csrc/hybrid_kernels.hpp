@@ -66,7 +66,8 @@ struct MidCoop {          // what the safety net needs beside the two arrays (ta
 
 template <typename E, int NT, int K>
 __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table, uint32_t* __restrict__ totals,
-                                              uint32_t* bar, uint32_t* fault, unsigned char* smem, int key_bits = 32)
+                                              uint32_t* bar, uint32_t* fault, unsigned char* smem, int key_bits = 32,
+                                              uint32_t target0 = 0u /* what the barrier counter has reached on entry */)
 {
     using C = TileCfg<E, 8, NT, K>;
     constexpr int NW = NT / 64;
@@ -82,7 +83,7 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
     const uint32_t t1 = t0 + per < tiles ? t0 + per : tiles;
     const uint32_t e0 = t0 * (uint32_t)C::TILE;
     const uint32_t e1 = (uint64_t)t1 * C::TILE < n ? t1 * (uint32_t)C::TILE : n;
-    uint32_t target = 0u;   // mid_prep_kernel leaves the barrier counter at zero (done[1])
+    uint32_t target = target0;   // the barrier counter is zero on entry unless the caller has used it already
     E* src = data;
     E* dst = tmp;
     for (int sb = 0; sb < key_bits; sb += 8) {   // 32: u32 keys and {key, value} pairs; 64: u64 keys (an even number of passes)
@@ -381,10 +382,19 @@ __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, c
 // is worse: up to 127 pads bump ONE counter, and same-address LDS atomics serialise.)
 // S = type of the stored elements: E, or uint16_t -- the large sort keeps only the low 16 bits of u32 keys in its second slab
 // (the bits above are the segment's number) and `hi` puts them back at the final store.
-template <typename E, int R, int F, typename S>
-__device__ __forceinline__ void wave_sort_rows(const S* __restrict__ src, E* __restrict__ dst, uint32_t m, int lane,
-                                               E* __restrict__ buf, uint32_t* __restrict__ cnt, uint32_t low_bits, E hi)
+// SOA: the destination is two u32 arrays (keys = dst reinterpreted, values = dst_vals), E = {key, value} as one u64.
+template <typename E, int R, int F, typename S, bool SOA>
+__device__ __forceinline__ void wave_sort_rows(const S* __restrict__ src, E* __restrict__ dst, uint32_t* __restrict__ dst_vals, uint32_t m,
+                                               int lane, E* __restrict__ buf, uint32_t* __restrict__ cnt, uint32_t low_bits, E hi)
 {
+    auto put = [&](int idx, E x) {
+        if constexpr (SOA) {
+            reinterpret_cast<uint32_t*>(dst)[idx] = (uint32_t)x;
+            dst_vals[idx] = (uint32_t)((unsigned long long)x >> 32);
+        } else {
+            dst[idx] = x;
+        }
+    };
     const int rem = (int)m - lane;   // item j of this lane exists iff j*64 < rem
     E e[R];
 #pragma unroll
@@ -394,7 +404,7 @@ __device__ __forceinline__ void wave_sort_rows(const S* __restrict__ src, E* __r
     if (npass == 0) {   // nothing left to sort (the digits above covered every bit that varies): the segment only moves
 #pragma unroll
         for (int j = 0; j < R; ++j)
-            if (j < F || j * 64 < rem) dst[j * 64 + lane] = e[j] | hi;
+            if (j < F || j * 64 < rem) put(j * 64 + lane, e[j] | hi);
         return;
     }
     int sb = 0;
@@ -433,32 +443,34 @@ __device__ __forceinline__ void wave_sort_rows(const S* __restrict__ src, E* __r
     }
 #pragma unroll
     for (int j = 0; j < R; ++j)
-        if (j < F || j * 64 < rem) dst[j * 64 + lane] = buf[j * 64 + lane] | hi;
+        if (j < F || j * 64 < rem) put(j * 64 + lane, buf[j * 64 + lane] | hi);
 }
 
 // rows -> the smallest body that holds them: bodies for RMIN (any number of rows up to RMIN: every row tested), RMIN + STEP,
 // ..., K rows.  A kernel for large tiles (K = 40, 80: segments of the large sort beyond 64 Mi keys) starts at K / 2 -- its
 // segments are that large -- and steps by 4 to keep the code size in bounds.
-template <typename E, int R, int K, int STEP, bool FIRST, typename S>
-__device__ __forceinline__ void wave_sort_dispatch(int rows, const S* __restrict__ src, E* __restrict__ dst, uint32_t m, int lane,
-                                                   E* __restrict__ buf, uint32_t* __restrict__ cnt, uint32_t low_bits, E hi)
+template <typename E, int R, int K, int STEP, bool FIRST, typename S, bool SOA>
+__device__ __forceinline__ void wave_sort_dispatch(int rows, const S* __restrict__ src, E* __restrict__ dst, uint32_t* __restrict__ dst_vals,
+                                                   uint32_t m, int lane, E* __restrict__ buf, uint32_t* __restrict__ cnt, uint32_t low_bits,
+                                                   E hi)
 {
     constexpr int RR = R < K ? R : K;
     constexpr int F = FIRST ? 0 : RR - STEP;
     if constexpr (R >= K) {
-        wave_sort_rows<E, RR, F, S>(src, dst, m, lane, buf, cnt, low_bits, hi);
+        wave_sort_rows<E, RR, F, S, SOA>(src, dst, dst_vals, m, lane, buf, cnt, low_bits, hi);
     } else {
-        if (rows <= R) wave_sort_rows<E, RR, F, S>(src, dst, m, lane, buf, cnt, low_bits, hi);
-        else wave_sort_dispatch<E, R + STEP, K, STEP, false, S>(rows, src, dst, m, lane, buf, cnt, low_bits, hi);
+        if (rows <= R) wave_sort_rows<E, RR, F, S, SOA>(src, dst, dst_vals, m, lane, buf, cnt, low_bits, hi);
+        else wave_sort_dispatch<E, R + STEP, K, STEP, false, S, SOA>(rows, src, dst, dst_vals, m, lane, buf, cnt, low_bits, hi);
     }
 }
 
-template <typename E, int K, int WAVES, int STEP, int RMIN, typename S>
+template <typename E, int K, int WAVES, int STEP, int RMIN, typename S, bool SOA>
 __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* in, E* out, const uint32_t* __restrict__ seg_start,
                                                                         uint32_t num_segments, uint32_t low_bits, uint32_t* fault,
                                                                         const uint32_t* __restrict__ seg_cnt, uint32_t in_stride,
                                                                         const uint32_t* __restrict__ gate,
-                                                                        const uint32_t* __restrict__ dyn_low_bits)
+                                                                        const uint32_t* __restrict__ dyn_low_bits,
+                                                                        uint32_t* out_vals /* SOA: out = the key array */)
 {
     if (gate && *gate != 0u) return;
     if (dyn_low_bits) low_bits = *dyn_low_bits;
@@ -479,14 +491,21 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
         if (lane == 0) atomicOr(fault + 1, 0x40000u);
         return;
     }
-    if constexpr (sizeof(S) == sizeof(E)) {
+    if constexpr (SOA) {
+        const E* src = in + (size_t)seg * in_stride;
+        wave_sort_dispatch<E, RMIN, K, STEP, true, E, true>((int)((m + 63u) >> 6), src,
+                                                            reinterpret_cast<E*>(reinterpret_cast<uint32_t*>(out) + begin),
+                                                            out_vals + begin, m, lane, buf, cnt, low_bits, E(0));
+    } else if constexpr (sizeof(S) == sizeof(E)) {
         const E* src = in + (seg_cnt ? (size_t)seg * in_stride : (size_t)begin);
-        wave_sort_dispatch<E, RMIN, K, STEP, true, E>((int)((m + 63u) >> 6), src, out + begin, m, lane, buf, cnt, low_bits, E(0));
+        wave_sort_dispatch<E, RMIN, K, STEP, true, E, false>((int)((m + 63u) >> 6), src, out + begin, nullptr, m, lane, buf, cnt,
+                                                             low_bits, E(0));
     } else {
         // slab form with 16-bit elements: the key's bits above low_bits are (sampled prefix, segment number)
         const S* src = reinterpret_cast<const S*>(in) + (size_t)seg * in_stride;
         const E hi = (E)(((dyn_low_bits[1] << 16) | seg) << low_bits);
-        wave_sort_dispatch<E, RMIN, K, STEP, true, S>((int)((m + 63u) >> 6), src, out + begin, m, lane, buf, cnt, low_bits, hi);
+        wave_sort_dispatch<E, RMIN, K, STEP, true, S, false>((int)((m + 63u) >> 6), src, out + begin, nullptr, m, lane, buf, cnt,
+                                                             low_bits, hi);
     }
 }
 
@@ -883,6 +902,8 @@ struct LookbackPass {
     uint32_t rows_per_chain_a;    // ... rows_per_chain of pass A
     uint32_t dst_stride;          // elements per destination slab
     uint32_t dst_total;
+    const uint32_t* soa_keys;     // pass A of an SoA sort: the input is two u32 arrays (src unused), packed to {key, value} on load
+    const uint32_t* soa_vals;
 };
 
 template <typename E, int NT, int K>
@@ -977,7 +998,14 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
     const uint32_t wbase = (uint32_t)(w * 64 * K + lane);
     E e[K];
     const uint32_t lin = a.which_digit == 1 ? base : s_misc[3];   // index of the tile's first element if it is one stretch
-    if (lin != 0xffffffffu) {
+    if (a.soa_keys) {
+        const int rem = (int)valid - (int)wbase;
+        const uint32_t* __restrict__ kp = a.soa_keys + (size_t)lin + wbase;
+        const uint32_t* __restrict__ vp = a.soa_vals + (size_t)lin + wbase;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            e[j] = (j * 64 < rem) ? ((E)kp[j * 64] | ((E)vp[j * 64] << 32)) : ~E(0);
+    } else if (lin != 0xffffffffu) {
         const typename IO::Cursor p = io.cursor((size_t)lin + wbase);
         if (valid == (uint32_t)C::TILE) {
 #pragma unroll
@@ -1117,7 +1145,8 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
                                                             uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_off,
                                                             uint32_t* __restrict__ mode, uint32_t* host_mode, uint32_t n,
                                                             const StablePlace* __restrict__ place, E* data, E* tmp,
-                                                            uint32_t* __restrict__ ctable, uint32_t* fault)
+                                                            uint32_t* __restrict__ ctable, uint32_t* fault, uint32_t* soa_keys,
+                                                            uint32_t* soa_vals)
 {
     __shared__ uint32_t s_wsum[256 / 64 + 1];
     __shared__ uint32_t s_misc[4];
@@ -1161,7 +1190,20 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
     }
     if (overflow) {   // `bar` is zero here: msd2s_prep_kernel, the first launch of every sort, clears it
         __syncthreads();
-        coop_lsd_sort<E, 256, 16>(data, tmp, n, ctable, ctable + 256 * 256, bar, fault, smem, 32);
+        uint32_t target = 0u;
+        if (soa_keys) {   // SoA input: pack it into `data` (here: the first slab area), sort that, unpack
+            for (size_t i = (size_t)blockIdx.x * 256u + (size_t)t; i < n; i += (size_t)gridDim.x * 256u)
+                data[i] = (E)soa_keys[i] | ((E)soa_vals[i] << 32);
+            if (!grid_barrier(bar, target, gridDim.x, fault)) return;
+        }
+        coop_lsd_sort<E, 256, 16>(data, tmp, n, ctable, ctable + 256 * 256, bar, fault, smem, 32, target);
+        if (soa_keys) {   // the sort's last phase ends with a grid barrier: `data` is complete
+            for (size_t i = (size_t)blockIdx.x * 256u + (size_t)t; i < n; i += (size_t)gridDim.x * 256u) {
+                const E x = data[i];
+                soa_keys[i] = (uint32_t)x;
+                soa_vals[i] = (uint32_t)(x >> 32);
+            }
+        }
     }
 }
 

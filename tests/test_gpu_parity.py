@@ -1245,6 +1245,20 @@ def test_large_pairs_stable_msd_passes_with_lookback(dev):
         pairs[4321] |= np.uint64(0xf0000000)
         pairs[n - 5] |= np.uint64(0x80000000)
         assert np.array_equal(gpu_sort_kv(dev, p, pairs), oracle.sort_kv32(pairs)), "outliers"
+        # the same path for separate key and value arrays (SoA): packed on load, split by the finish; the safety net packs
+        # the input into the slab area, sorts it there and splits it back
+        for nm, pairs in (("SoA uniform", oracle.pairs_kv32(n, seed=11)), ("SoA 20-bit keys", cases["20-bit keys (every key ~8 times)"]),
+                          ("SoA all keys equal (safety net)", cases["all keys equal"]),
+                          ("SoA uniform, 3000001", oracle.pairs_kv32(3000001, seed=12))):
+            pairs = pairs.astype(np.uint64)
+            m = pairs.size
+            kb, vb = Buffer(dev, m, np.uint32), Buffer(dev, m, np.uint32)
+            kb.write((pairs & np.uint64(0xffffffff)).astype(np.uint32)); vb.write((pairs >> np.uint64(32)).astype(np.uint32))
+            p.radixSortSoA(dev, kb, vb, m, 32)
+            want = oracle.sort_kv32(pairs)
+            assert np.array_equal(kb.toHost(), (want & np.uint64(0xffffffff)).astype(np.uint32)), nm
+            assert np.array_equal(vb.toHost(), (want >> np.uint64(32)).astype(np.uint32)), nm
+            kb.release(); vb.release()
         DeviceUtils.waitForCompletion(dev)
         dev.setParam("sort.msd2", 1)
         for i in range(4):   # the automatic choice, friendly and skewed inputs alternating
