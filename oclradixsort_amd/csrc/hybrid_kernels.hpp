@@ -428,12 +428,25 @@ __device__ __forceinline__ void wave_sort_rows(const S* __restrict__ src, E* __r
             o.w = o.z + c.z;
             *reinterpret_cast<u32x4*>(cnt + 4 * lane) = o;
         }
+        // slots: one returning atomic per element, then its store.  Small tiles (many waves per CU) go element by element; the
+        // large tiles of the big segments (K = 40, 80: one to four waves per CU) would sit out one LDS round trip per element,
+        // so they take their slots eight at a time
+        constexpr int B = R > 20 ? 8 : 1;   // 16 for the largest tile measured the same
 #pragma unroll
-        for (int j = 0; j < R; ++j)
-            if (j < F || j * 64 < rem) {
-                const uint32_t pos = __hip_atomic_fetch_add(&cnt[digit(e[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                buf[pos] = e[j];
+        for (int j0 = 0; j0 < R; j0 += B) {
+            uint32_t pos[B];
+#pragma unroll
+            for (int jj = 0; jj < B; ++jj) {
+                const int j = j0 + jj;
+                if (j < R && (j < F || j * 64 < rem))
+                    pos[jj] = __hip_atomic_fetch_add(&cnt[digit(e[j < R ? j : R - 1])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
+#pragma unroll
+            for (int jj = 0; jj < B; ++jj) {
+                const int j = j0 + jj;
+                if (j < R && (j < F || j * 64 < rem)) buf[pos[jj]] = e[j < R ? j : R - 1];
+            }
+        }
         if (p + 1 < npass) {
 #pragma unroll
             for (int j = 0; j < R; ++j)

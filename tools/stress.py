@@ -19,7 +19,7 @@ d = DeviceUtils.allocate(); p = Pprims()
 d2 = DeviceUtils.allocate(); selftests = 0
 rng = np.random.RandomState(2026)
 t_end = time.time() + args.seconds
-it = 0; elems = 0
+it = 0; elems = 0; t_mark = time.time()
 def checks(a):
     a64 = a.astype(np.uint64)
     return int(a64.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(a64)) if a.size else 0
@@ -73,6 +73,8 @@ while time.time() < t_end:
         b = Buffer(d, n, np.uint64); b.write(k64); p.radixSort64(d, b, n); out = b.toHost(); b.release()
         assert np.all(out[1:] >= out[:-1]) and checks(out) == checks(k64), (it, kind, n, algo, bits, tile, dist)
     elems += n
+    if time.time() - t_mark > 60:   # a sign of life for the runner
+        t_mark = time.time(); print("... %d sorts, %.0f M elements" % (it, elems / 1e6), flush=True)
 print("stress ok: %d sorts, %.1f M elements, %.0f s, no mismatch, no look-back fault, %d LDS-order self-tests beside running sorts: 0 mismatches"
       % (it, elems / 1e6, args.seconds, selftests))
 p.close(); DeviceUtils.deallocate(d); DeviceUtils.deallocate(d2)
