@@ -1269,3 +1269,41 @@ def test_large_pairs_stable_msd_passes_with_lookback(dev):
     finally:
         dev.setParam("sort.msd2", 1)
         p.close()
+
+
+def test_large_sort_safety_net_runs_inside_its_offsets_kernel(dev):
+    """Keys that cannot fit the slabs (all equal) with "sort.msd2" forced on: no kernel of another path is launched -- the five
+    launches of the large sort are all there is -- the offsets kernel is where the time goes (its workgroups run the cooperative
+    LSD sort), the finish returns at once, and the result is right."""
+    n = (1 << 24) + 5
+    keys = np.full(n, 0x0badf00d, dtype=np.uint32)
+    keys[::7] = 0x12345678
+    dev.setParam("sort.msd2", 2)
+    p = Pprims()
+    b = Buffer(dev, n, np.uint32)
+    try:
+        b.write(keys)
+        dev.toggleProfiling(True)
+        dev.profile(reset=True)
+        p.radixSort(dev, b, n)
+        prof = dev.profile(reset=True)
+        dev.toggleProfiling(False)
+        assert set(prof) == {"msd2_sample", "msd2_pass1_u32", "msd2_pass2_u32", "msd2_offsets", "segment_sort_wave_u32"}, prof
+        assert prof["msd2_offsets"][1] > 10 * prof["segment_sort_wave_u32"][1], prof   # the sort happened there; the finish left
+        assert np.array_equal(b.toHost(), np.sort(keys))
+        # a friendly input on the same handle: the offsets kernel is back to microseconds
+        k2 = oracle.keys_u32(n, seed=77)
+        b.write(k2)
+        dev.toggleProfiling(True)
+        dev.profile(reset=True)
+        p.radixSort(dev, b, n)
+        prof = dev.profile(reset=True)
+        dev.toggleProfiling(False)
+        assert prof["msd2_offsets"][1] < 0.1 and prof["msd2_offsets"][1] < prof["segment_sort_wave_u32"][1], prof
+        assert np.array_equal(b.toHost(), oracle.sort_u32(k2))
+    finally:
+        dev.toggleProfiling(False)
+        dev.setParam("sort.msd2", 1)
+        b.release()
+        p.close()
+
