@@ -301,10 +301,40 @@ __device__ __forceinline__ void rank_in_wave(const E (&e)[K], uint32_t (&rnk)[K]
 #pragma unroll
             for (int j = 1; j < K; ++j) same &= digit_of<NBITS>(e[j], start_bit) == d0;
         }
+        // second screen, again on ONE element per lane: how many lanes start a run (digit differs from the left neighbour's;
+        // row_shr:1, the first lane of each row of 16 always counts).  Few runs = sorted / clustered input: a wave then holds
+        // two or three digits and every returning atomic would still queue ~30 lanes on one counter (~25 cycles each: the
+        // second MSD pass of the large sort took 0.30 ms instead of 0.12 on sorted keys).
+        const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)~dg0, (int)dg0, 0x111, 0xf, 0xf, false);
+        const bool few_runs = __popcll(__ballot(left != dg0)) <= 8;
         if (__all(same)) {
 #pragma unroll
             for (int j = 0; j < K; ++j) rnk[j] = (uint32_t)(j * 64 + lane_id());
             if (lane_id() == 0) __hip_atomic_store(&my_wcnt[d0], (uint32_t)(64 * K), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else if (few_runs) {
+            // per instruction: the lanes of one digit are served together -- ONE returning add of their number by their first
+            // lane, every lane's rank = the value it returned + the lanes of the group below it (the order the lane-ordered
+            // atomics would have produced).  Up to four digits that way; lanes left over take the plain atomic.
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint32_t d = digit_of<NBITS>(e[j], start_bit);
+                uint64_t todo = __ballot(true);
+                uint32_t r = 0u;
+#pragma unroll 1
+                for (int it = 0; it < 4 && todo; ++it) {
+                    const int lead = __builtin_ctzll(todo);
+                    const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, lead);
+                    const uint64_t m = __ballot(d == dl);
+                    uint32_t old = 0u;
+                    if (lane_id() == lead)
+                        old = __hip_atomic_fetch_add(&my_wcnt[dl], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    old = (uint32_t)__builtin_amdgcn_readlane((int)old, lead);
+                    if (d == dl) r = old + mbcnt64(m);
+                    todo &= ~m;
+                }
+                if ((todo >> lane_id()) & 1ull) r = __hip_atomic_fetch_add(&my_wcnt[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                rnk[j] = r;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
