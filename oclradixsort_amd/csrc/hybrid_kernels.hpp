@@ -408,10 +408,27 @@ __device__ __forceinline__ void wave_sort_rows(const S* __restrict__ src, E* __r
         return;
     }
     int sb = 0;
+    bool in_regs = true;   // the current order is in e[] (always, except after a final pass that ran)
     for (int p = 0; p < npass; ++p) {
         const int nb = ((int)low_bits - sb + (npass - p - 1)) / (npass - p);
         const uint32_t mask = (1u << nb) - 1u;
         auto digit = [&](E x) -> uint32_t { return (uint32_t)(x >> sb) & mask; };
+        {   // a pass in which every element has the same digit changes nothing -- and would queue all 64 lanes of every
+            // atomic on ONE counter (keys that are multiples of 65536: the finish took 0.91 ms instead of 0.12 at 64 Mi keys).
+            // Screen on one element per lane, exact test only when it passes.
+            const uint32_t dg0 = digit(e[0]);   // row 0 is full, or the lane's item is missing: then any value will do
+            const uint32_t df = (uint32_t)__builtin_amdgcn_readfirstlane((int)dg0);
+            if (__all(dg0 == df || rem <= 0)) {
+                bool same = true;
+#pragma unroll
+                for (int j = 1; j < R; ++j)
+                    if (j < F || j * 64 < rem) same &= digit(e[j]) == df;
+                if (__all(same)) {
+                    sb += nb;
+                    continue;
+                }
+            }
+        }
         const u32x4 z = {0u, 0u, 0u, 0u};
         *reinterpret_cast<u32x4*>(cnt + 4 * lane) = z;
 #pragma unroll
@@ -451,8 +468,16 @@ __device__ __forceinline__ void wave_sort_rows(const S* __restrict__ src, E* __r
 #pragma unroll
             for (int j = 0; j < R; ++j)
                 if (j < F || j * 64 < rem) e[j] = buf[j * 64 + lane];
+        } else {
+            in_regs = false;
         }
         sb += nb;
+    }
+    if (in_regs) {   // the last pass (or every pass) had nothing to do
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (j < F || j * 64 < rem) put(j * 64 + lane, e[j] | hi);
+        return;
     }
 #pragma unroll
     for (int j = 0; j < R; ++j)
