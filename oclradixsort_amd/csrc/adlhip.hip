@@ -896,7 +896,9 @@ Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
 {
     Msd2Layout L;
     const uint32_t tile = elem_bytes == 4 ? 16384u : 8192u;   // TileCfg<E, 8, 512, 32 | 16>
-    L.stride_a = (uint32_t)align_up(n / 256 + n / 8192 + 4096, 64);   // mean bucket + 3 % + 4096
+    // mean bucket + 25 % + 4096: the head-room of the segment slabs below (1280 for a mean of 1024), so that keys whose density
+    // varies by up to a quarter over the key range stay on this path (with + 3 % any mild skew went to the safety net)
+    L.stride_a = (uint32_t)align_up(n / 256 + n / 1024 + 4096, 64);
     L.stride_b = msd2_stride_b(n);
     L.tiles_per_bucket = (L.stride_a + tile - 1) / tile;
     L.off_mode = 0;
@@ -1035,7 +1037,7 @@ Msd2sLayout msd2s_layout(size_t n)
         const size_t mean = slice / 256;
         size_t sd = 1;
         while (sd * sd < mean) ++sd;
-        const size_t stride = align_up(mean + 8 * sd + 64, 64);
+        const size_t stride = align_up(mean + mean / 4 + 8 * sd + 64, 64);   // + 25 %: as much skew as the segment slabs take
         const double waste = (double)((stride + kMsd2sTile - 1) / kMsd2sTile) * kMsd2sTile / (double)mean;
         if (waste < best - 1e-9) {
             best = waste;
@@ -1062,7 +1064,7 @@ Msd2sLayout msd2s_layout(size_t n)
     // rows of pass A <= n/tile + 16, rows of a bucket in pass B <= its sub-slabs / tile + 16
     size_t sdb = 1;
     while (sdb * sdb * 4096 < n) ++sdb;   // >= sd of every choice (a sub-slab's mean is at most n / 4096 + 32)
-    const size_t bucket_bound = n / 256 + 24 * (32 + 8 * (sdb + 1) + 128);
+    const size_t bucket_bound = n / 256 + n / 1024 + 24 * (32 + 8 + 8 * (sdb + 1) + 128);
     const size_t rows_a_bound = n / kMsd2sTile + 24;
     const size_t rows_b_bound = bucket_bound / kMsd2sTile + 25;
     L.off_status_a = align_up(L.off_tickets + (size_t)L.ticket_words * 4, 256);

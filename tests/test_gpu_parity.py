@@ -1134,6 +1134,9 @@ def test_large_keys_only_sort_two_msd_passes_and_lds_finish(dev):
         skewed = {
             "below 2^24": u >> np.uint32(8),
             "one heavy top byte": np.where(np.arange(n) % 10 != 0, u >> np.uint32(8), u).astype(np.uint32),
+            "lower half of the range 1.2 x as dense": np.where(np.arange(n) % 5 == 0, u >> np.uint32(1), u).astype(np.uint32),
+            "low 16 bits constant (the finish has nothing to do)": u & np.uint32(0xffff0000),
+            "low byte constant": u & np.uint32(0xffffff00),
             "second byte constant": u & np.uint32(0xff00ffff),
             "all equal": np.full(n, 0xdeadbeef, dtype=np.uint32),
             "sorted": np.sort(u),
