@@ -133,7 +133,7 @@ int adlhip_unmap(adlhip_device* dev, void* dptr, void* hptr, size_t bytes);
  *   *tmp_bytes  : second data buffer, n elements
  *   *work_bytes : control scratch (digit tables / tile status words) and, for the sizes the large sort takes
  *                 ("sort.msd2": full-key sorts of more than 1 Mi elements), its bucket and segment slabs -- about
- *                 2.3 x n elements (64 Mi u32 keys: 0.62 GB; 64 Mi pairs: 1.3 GB; 256 Mi u64 keys: 4.9 GB).  The value
+ *                 2.3 - 3.3 x n elements (64 Mi u32 keys: 0.61 GB; 64 Mi pairs: 1.7 GB; 256 Mi u64 keys: 5.9 GB).  The value
  *                 suffices for EVERY n' <= n with the current knobs (the need of a single n is not monotone:
  *                 smaller inputs use smaller tiles and so more status rows), so a caller may size its scratch
  *                 once for its largest batch; changing "sort.tile", "sort.digit_bits" or "sort.algo" later can

@@ -675,7 +675,7 @@ int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32
     constexpr size_t per_wave = sizeof(E) * 64 * K + 256 * 4;
     constexpr int WAVES = per_wave <= 6144 ? 8 : per_wave <= 12288 ? 4 : per_wave <= 24576 ? 2 : 1;
     constexpr int STEP = K <= 40 ? 2 : 4;        // row-count bodies: every 2 rows, every 4 for the largest tile
-    constexpr int RMIN = K <= 20 ? 2 : K / 2;    // the tiles beyond 20 rows exist for segments that need them
+    constexpr int RMIN = K <= 24 ? 2 : K / 2;    // the tiles beyond 24 rows exist for segments that need them
     auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES, STEP, RMIN, S, SOA>;
     const size_t lds = (size_t)WAVES * per_wave;
     if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
@@ -881,24 +881,28 @@ struct Msd2Layout {
 };
 
 // slab of a segment = the smallest of the finish's tiles that holds its mean + 7.5 standard deviations of a uniform key
-// distribution (64 Mi keys: 1024 + 240 of 1280; a segment beyond its slab sends the sort to the safety net, it is never
+// distribution (64 Mi keys: 1024 + 240 = 1264, slab 1536; a segment beyond its slab sends the sort to the safety net, it is never
 // wrong; at 7.5 sd that is one sort in 10^8)
+// slab and finish tile of the first tier: 64 * 24 elements.  With 64 * 20 = 1280 (mean 1024 at 64 Mi keys + 7.5 sd) keys whose
+// density varied by 20 % over the key range already went to the safety net; 1536 takes ~45 % and costs nothing measurable
+// (finish 118.0 vs 118.3 us at 64 Mi keys: five workgroups of four waves per CU instead of three of eight)
+constexpr uint32_t kMsd2Stride0 = 1536;
 uint32_t msd2_stride_b(size_t n)
 {
     const size_t mean = (n + 65535) / 65536;
     size_t sd = 1;
     while (sd * sd < mean) ++sd;
     const size_t need = mean + (15 * sd + 1) / 2;
-    return need <= 1280 ? 1280u : need <= 2560 ? 2560u : 5120u;
+    return need <= 1280 ? kMsd2Stride0 : need <= 2560 ? 2560u : 5120u;   // (the tiers' bounds on the mean stay as they were)
 }
 
 Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
 {
     Msd2Layout L;
     const uint32_t tile = elem_bytes == 4 ? 16384u : 8192u;   // TileCfg<E, 8, 512, 32 | 16>
-    // mean bucket + 25 % + 4096: the head-room of the segment slabs below (1280 for a mean of 1024), so that keys whose density
-    // varies by up to a quarter over the key range stay on this path (with + 3 % any mild skew went to the safety net)
-    L.stride_a = (uint32_t)align_up(n / 256 + n / 1024 + 4096, 64);
+    // mean bucket + 50 % + 4096: the head-room of the segment slabs below (1536 for a mean of 1024), so that keys whose density
+    // varies by up to ~45 % over the key range stay on this path (with + 3 % any mild skew went to the safety net)
+    L.stride_a = (uint32_t)align_up(n / 256 + n / 512 + 4096, 64);
     L.stride_b = msd2_stride_b(n);
     L.tiles_per_bucket = (L.stride_a + tile - 1) / tile;
     L.off_mode = 0;
@@ -1005,7 +1009,7 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     // the finish sorts the bits below the second digit (the offsets kernel has published how many), a wave per segment
     const uint32_t* lowb = mode + adlhip::kDynLowBits;
     using S = typename std::conditional<sizeof(E) == 4, uint16_t, E>::type;   // what pass 2 wrote
-    if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
+    if (L.stride_b == kMsd2Stride0) rc = launch_wave_segment_sort<E, kMsd2Stride0 / 64, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
     else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
     else rc = launch_wave_segment_sort<E, 80, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
     if (rc) return rc;
@@ -1037,7 +1041,7 @@ Msd2sLayout msd2s_layout(size_t n)
         const size_t mean = slice / 256;
         size_t sd = 1;
         while (sd * sd < mean) ++sd;
-        const size_t stride = align_up(mean + mean / 4 + 8 * sd + 64, 64);   // + 25 %: as much skew as the segment slabs take
+        const size_t stride = align_up(mean + mean / 2 + 8 * sd + 64, 64);   // + 50 %: as much skew as the segment slabs take
         const double waste = (double)((stride + kMsd2sTile - 1) / kMsd2sTile) * kMsd2sTile / (double)mean;
         if (waste < best - 1e-9) {
             best = waste;
@@ -1064,7 +1068,7 @@ Msd2sLayout msd2s_layout(size_t n)
     // rows of pass A <= n/tile + 16, rows of a bucket in pass B <= its sub-slabs / tile + 16
     size_t sdb = 1;
     while (sdb * sdb * 4096 < n) ++sdb;   // >= sd of every choice (a sub-slab's mean is at most n / 4096 + 32)
-    const size_t bucket_bound = n / 256 + n / 1024 + 24 * (32 + 8 + 8 * (sdb + 1) + 128);
+    const size_t bucket_bound = n / 256 + n / 512 + 24 * (32 + 16 + 8 * (sdb + 1) + 128);
     const size_t rows_a_bound = n / kMsd2sTile + 24;
     const size_t rows_b_bound = bucket_bound / kMsd2sTile + 25;
     L.off_status_a = align_up(L.off_tickets + (size_t)L.ticket_words * 4, 256);
@@ -1157,12 +1161,12 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     const uint32_t* lowb = mode + adlhip::kDynLowBits;
     if (soa_keys) {   // the finish writes keys and values to their own arrays
         E* ko = reinterpret_cast<E*>(soa_keys);
-        if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
+        if (L.stride_b == kMsd2Stride0) rc = launch_wave_segment_sort<E, kMsd2Stride0 / 64, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
         else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
         else rc = launch_wave_segment_sort<E, 80, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
         return rc;
     }
-    if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
+    if (L.stride_b == kMsd2Stride0) rc = launch_wave_segment_sort<E, kMsd2Stride0 / 64>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
     else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
     else rc = launch_wave_segment_sort<E, 80>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
     return rc;

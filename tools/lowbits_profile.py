@@ -10,8 +10,9 @@ n = 1 << 26
 w = Buffer(d, n, np.uint32)
 u = oracle.keys_u32(n, seed=3)
 mild = np.where(np.arange(n) % 5 == 0, u >> np.uint32(1), u).astype(np.uint32)   # lower half of the range 1.2 x as dense
+mild14 = np.where(np.arange(n) % 5 < 2, u >> np.uint32(1), u).astype(np.uint32)   # lower half 1.4 x as dense
 for label, keys in (("low 16 bits zero", u & np.uint32(0xffff0000)), ("low 8 bits zero", u & np.uint32(0xffffff00)),
-                    ("mild skew (1.2x)", mild), ("uniform", u)):
+                    ("uniform", u), ("mild skew (1.2x)", mild), ("mild skew (1.4x)", mild14)):
     for rep in range(2):
         w.write(keys, n); DeviceUtils.waitForCompletion(d)
         d.toggleProfiling(True); d.profile(reset=True)
