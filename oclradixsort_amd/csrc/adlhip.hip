@@ -673,7 +673,7 @@ int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32
 {
     // a wave's LDS: its tile + 256 counters; waves per workgroup so that a workgroup takes at most ~48 KiB (three per CU)
     constexpr size_t per_wave = sizeof(E) * 64 * K + 256 * 4;
-    constexpr int WAVES = per_wave <= 6144 ? 8 : per_wave <= 12288 ? 4 : per_wave <= 24576 ? 2 : 1;
+    constexpr int WAVES = per_wave <= 6144 ? 8   /* eight waves with the 7 KiB of the 1536-element tile measured slower */ : per_wave <= 12288 ? 4 : per_wave <= 24576 ? 2 : 1;
     constexpr int STEP = K <= 40 ? 2 : 4;        // row-count bodies: every 2 rows, every 4 for the largest tile
     constexpr int RMIN = K <= 24 ? 2 : K / 2;    // the tiles beyond 24 rows exist for segments that need them
     auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES, STEP, RMIN, S, SOA>;
@@ -893,7 +893,8 @@ uint32_t msd2_stride_b(size_t n)
     size_t sd = 1;
     while (sd * sd < mean) ++sd;
     const size_t need = mean + (15 * sd + 1) / 2;
-    return need <= 1280 ? kMsd2Stride0 : need <= 2560 ? 2560u : 5120u;   // (the tiers' bounds on the mean stay as they were)
+    // (the tiers' bounds on the mean stay as they were; up to a mean of ~640 the 1280-element tile already leaves 1.5 x)
+    return need <= 832 ? 1280u : need <= 1280 ? kMsd2Stride0 : need <= 2560 ? 2560u : 5120u;
 }
 
 Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
@@ -1009,7 +1010,8 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     // the finish sorts the bits below the second digit (the offsets kernel has published how many), a wave per segment
     const uint32_t* lowb = mode + adlhip::kDynLowBits;
     using S = typename std::conditional<sizeof(E) == 4, uint16_t, E>::type;   // what pass 2 wrote
-    if (L.stride_b == kMsd2Stride0) rc = launch_wave_segment_sort<E, kMsd2Stride0 / 64, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
+    if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
+    else if (L.stride_b == kMsd2Stride0) rc = launch_wave_segment_sort<E, kMsd2Stride0 / 64, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
     else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
     else rc = launch_wave_segment_sort<E, 80, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
     if (rc) return rc;
@@ -1161,12 +1163,14 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     const uint32_t* lowb = mode + adlhip::kDynLowBits;
     if (soa_keys) {   // the finish writes keys and values to their own arrays
         E* ko = reinterpret_cast<E*>(soa_keys);
-        if (L.stride_b == kMsd2Stride0) rc = launch_wave_segment_sort<E, kMsd2Stride0 / 64, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
+        if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
+        else if (L.stride_b == kMsd2Stride0) rc = launch_wave_segment_sort<E, kMsd2Stride0 / 64, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
         else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
         else rc = launch_wave_segment_sort<E, 80, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
         return rc;
     }
-    if (L.stride_b == kMsd2Stride0) rc = launch_wave_segment_sort<E, kMsd2Stride0 / 64>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
+    if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
+    else if (L.stride_b == kMsd2Stride0) rc = launch_wave_segment_sort<E, kMsd2Stride0 / 64>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
     else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
     else rc = launch_wave_segment_sort<E, 80>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
     return rc;
