@@ -1212,7 +1212,9 @@ int run_sort(adlhip_device* d, Buf data, Buf tmp, void* work, size_t n, const st
     if (d->sort_algo < 0 && !seven) {   // automatic choice by size (profiles/r1_ncurve.txt)
         // the one-sweep path has more fixed cost (histogram, tables) and wins from ~24 MiB of data (fresh random keys,
         // profiles/r1_ncurve.txt: 4Mi u32 keys 78 vs 88 us, 8Mi 124 vs 117 us, 16Mi 224 vs 174 us)
-        if (n * Buf::kElemBytes < (size_t(24) << 20)) return three_kernel_sort<Buf>(d, data, tmp, work, n, plan);
+        // (AoS pairs: from ~36 MiB; 4 Mi pairs 0.103 vs 0.125 ms, 5 Mi pairs 0.149 vs 0.127 ms)
+        const size_t edge = (Buf::kElemBytes == 8 && !Buf::kSoa) ? (size_t(36) << 20) : (size_t(24) << 20);
+        if (n * Buf::kElemBytes < edge) return three_kernel_sort<Buf>(d, data, tmp, work, n, plan);
     }
     // tile status words carry 30-bit counts: beyond 2^30 elements use the table-based pass
     if (seven && n >= (size_t(1) << 30)) return fail("sort.digit_bits = 7 supports fewer than 2^30 elements");
