@@ -294,8 +294,10 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      device from a sample of the keys.  Keys only: runs are placed with atomic cursors (equal
  *                      keys are indistinguishable); pairs: by look-back, stably.  Keys that do not fit the slabs
  *                      are detected on the device and sorted by a cooperative LSD sort inside the same launches
- *                      (correct, slower); asynchronous hints then keep such a handle on the per-digit passes
- *                      (speed only).  2 forces the path from 1 Mi elements (tests)
+ *                      (correct, slower).  A handle first looks at a sample of its keys (riding along with one sort on
+ *                      the per-digit passes) and uses the path only after a good report; asynchronous reports keep a
+ *                      handle with unsuitable keys on the per-digit passes (speed only; results never depend on
+ *                      them).  2 forces the path from 1 Mi elements (tests)
  *   "profile"          0/1: bracket every kernel launch with hipEvents (Device::toggleProfiling,
  *                          Adl/Adl.h:142, AdlKernelUtilsCL.inl:654-677) */
 int adlhip_set_param(adlhip_device* dev, const char* name, int value);

@@ -87,6 +87,7 @@ struct adlhip_device {
     int mid_backoff = 32, mid2_backoff = 64;
     int msd2_path = 1;        // "sort.msd2": the large sort (msd2_sort for keys, msd2s_sort for pairs); 2 = forced (tests)
     int msd2_skip = 0, msd2_backoff = 32;   // sorts the next overflow report keeps off the large sort (x8 each time, reset by a success)
+    bool msd2_trusted = false;              // a good report has come in since the last bad one (msd2_decide)
     uint32_t* d_msd2 = nullptr;   // the large sort's handle-owned words, allocated on first use and zero between sorts: cursors of
                                   // pass 1 (256, one 128-byte line each) and pass 2 (65536), overflow flag, done counter, the safety
                                   // net's barrier counter, the four sample words
@@ -925,25 +926,49 @@ bool msd2_eligible(const adlhip_device* d, size_t elem_bytes, size_t n, int sort
     return n <= (elem_bytes == 4 ? kMsd2MaxU32 : kMsd2MaxU64);
 }
 
-// Host-side hint, as for the mid-size sort: after a sort whose keys did not fit the slabs (reported into pinned memory by
-// msd2_offsets_kernel, read here without synchronising) this handle's next 32 (256, 2048, 4096) eligible sorts go straight to
-// the per-digit passes; a success resets the count.  Only speed depends on it ("sort.msd2" = 2 forces the path, 0 = off).
-bool msd2_wanted(adlhip_device* d)
+// Host-side policy.  The kernels report into pinned memory what happened (1 = the keys fitted the slabs, 2 = they did not);
+// the host reads that word at the next call, without synchronising.
+//   * a handle that has no good report yet -- a fresh one, or one whose back-off has just run out -- does not risk the safety
+//     net (2.8 ms at 64 Mi keys): the sort takes the per-digit passes and msd2_probe_kernel rides along (~20 us), which says
+//     whether the keys' first digit would fit;
+//   * after a good report the handle uses the large sort;
+//   * after a bad one (from the probe or from a sort that went through its safety net) the next 32 (256, 2048, 4096)
+//     eligible sorts go straight to the per-digit passes, then the probe looks again.
+// Only speed depends on any of it ("sort.msd2" = 2 forces the path, 0 = off).
+enum Msd2Choice { kMsd2Skip = 0, kMsd2Use = 1, kMsd2Probe = 2 };
+Msd2Choice msd2_decide(adlhip_device* d)
 {
-    if (d->msd2_path == 2) return true;
+    if (d->msd2_path == 2) return kMsd2Use;
     if (d->msd2_skip > 0) {
         --d->msd2_skip;
-        return false;
+        return kMsd2Skip;
     }
     const uint32_t report = d->h_fault[11];
     d->h_fault[11] = 0u;
     if (report == 2u) {
+        d->msd2_trusted = false;
         d->msd2_skip = d->msd2_backoff;
         d->msd2_backoff = std::min(d->msd2_backoff * 8, 4096);
-        return false;
+        return kMsd2Skip;
     }
-    if (report == 1u) d->msd2_backoff = 32;
-    return true;
+    if (report == 1u) {
+        d->msd2_trusted = true;
+        d->msd2_backoff = 32;
+    }
+    return d->msd2_trusted ? kMsd2Use : kMsd2Probe;
+}
+
+// elem_bytes / key_bits of the array the keys are read from (AoS pairs: 8 / 32, the key is the low dword)
+int msd2_probe(adlhip_device* d, const void* keys, size_t elem_bytes, int key_bits, size_t n)
+{
+    return launch(d, "msd2_probe", [&] {
+        if (elem_bytes == 4)
+            hipLaunchKernelGGL(adlhip::msd2_probe_kernel<uint32_t>, dim3(1), dim3(1024), 0, d->stream, (const uint32_t*)keys, (uint32_t)n,
+                               key_bits, d->h_fault + 11);
+        else
+            hipLaunchKernelGGL(adlhip::msd2_probe_kernel<uint64_t>, dim3(1), dim3(1024), 0, d->stream, (const uint64_t*)keys, (uint32_t)n,
+                               key_bits, d->h_fault + 11);
+    });
 }
 
 template <typename E>
@@ -1253,9 +1278,17 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
         }
         if (form == 3) return mid_sort<E>(d, data, tmp, work, n);         // three launches
     }
-    if (msd2_eligible(d, sizeof(E), n, sort_bits, max_bits) && msd2_wanted(d)) return msd2_sort<E>(d, data, tmp, work, n);
+    if (msd2_eligible(d, sizeof(E), n, sort_bits, max_bits)) {
+        const Msd2Choice c = msd2_decide(d);
+        if (c == kMsd2Use) return msd2_sort<E>(d, data, tmp, work, n);
+        if (c == kMsd2Probe && msd2_probe(d, data, sizeof(E), max_bits, n)) return ADLHIP_FAILURE;
+    }
     if constexpr (sizeof(E) == 8) {
-        if (msd2s_eligible(d, sizeof(E), n, sort_bits, max_bits) && msd2_wanted(d)) return msd2s_sort(d, data, tmp, work, n);
+        if (msd2s_eligible(d, sizeof(E), n, sort_bits, max_bits)) {
+            const Msd2Choice c = msd2_decide(d);
+            if (c == kMsd2Use) return msd2s_sort(d, data, tmp, work, n);
+            if (c == kMsd2Probe && msd2_probe(d, data, 8, 32, n)) return ADLHIP_FAILURE;
+        }
     }
     return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, n, plan);
 }
@@ -1733,7 +1766,11 @@ int adlhip_radix_sort_soa32(adlhip_device* d, uint32_t* keys, uint32_t* vals, ui
     if (!vals || !tmp_vals) return fail("null value buffer passed to radix sort");
     if ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(tmp_vals)) & 15u)
         return fail("sort buffers must be 16-byte aligned");
-    if (msd2s_eligible(d, 8, n, sort_bits, 32) && msd2_wanted(d)) return msd2s_sort(d, nullptr, nullptr, work, n, keys, vals);
+    if (msd2s_eligible(d, 8, n, sort_bits, 32)) {
+        const Msd2Choice c = msd2_decide(d);
+        if (c == kMsd2Use) return msd2s_sort(d, nullptr, nullptr, work, n, keys, vals);
+        if (c == kMsd2Probe && msd2_probe(d, keys, 4, 32, n)) return ADLHIP_FAILURE;
+    }
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
     return run_sort<SoaBuf>(d, SoaBuf{keys, vals}, SoaBuf{tmp_keys, tmp_vals}, work, n, plan);
 }

@@ -607,6 +607,62 @@ __device__ __forceinline__ Msd2Placement msd2_placement(const uint32_t* __restri
     p.prefix = p.top < 64 ? (o >> p.top) : 0ull;
     return p;
 }
+// Before a device handle trusts the large sort with its keys it looks at them once: ONE workgroup samples 16 Ki keys, places
+// the first digit exactly as the sort would (msd2_placement's rule on the sample's OR / AND) and counts the samples per bucket;
+// a bucket with 1.75 x the mean (64 samples, + 6 sd) would not fit its slab.  The verdict goes into the same pinned
+// word the sort's own report uses (1 = fits, 2 = does not), to be read -- without synchronising -- by a later call; the sort
+// it rides along with takes the per-digit passes.  Costs ~20 us, once per handle (and once after every back-off); what it
+// saves is the safety net's 2.8 ms on the first sort of clustered / constant / low-entropy keys.  (Skew that only shows at
+// the scale of single segments is not seen here; the sort's own check remains.)
+template <typename E>
+__global__ __launch_bounds__(1024) void msd2_probe_kernel(const E* __restrict__ src, uint32_t n, int key_bits, uint32_t* host_report)
+{
+    __shared__ unsigned long long s_or[16], s_and[16];
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_top;
+    const int tid = (int)threadIdx.x;
+    const unsigned long long kmask = key_bits >= 64 ? ~0ull : ((1ull << key_bits) - 1ull);
+    unsigned long long v[16];
+    unsigned long long o = 0ull, a = ~0ull;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const unsigned long long k = (unsigned long long)(tid * 16 + i);
+        v[i] = (unsigned long long)src[(size_t)(k * (unsigned long long)n / 16384ull)] & kmask;
+        o |= v[i];
+        a &= v[i];
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        o |= __shfl_xor(o, sh);
+        a &= __shfl_xor(a, sh);
+    }
+    if ((tid & 63) == 0) {
+        s_or[tid >> 6] = o;
+        s_and[tid >> 6] = a;
+    }
+    if (tid < 256) s_hist[tid] = 0u;
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 16; ++i) {
+            o |= s_or[i];
+            a &= s_and[i];
+        }
+        const unsigned long long diff = o ^ a;
+        int top = diff ? 64 - __builtin_clzll(diff) : 0;
+        if (top < 16) top = 16;
+        s_top = (uint32_t)top;
+    }
+    __syncthreads();
+    const int sb = (int)s_top - 8;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) atomicAdd(&s_hist[(uint32_t)(v[i] >> sb) & 255u], 1u);
+    __syncthreads();
+    // mean 64 samples per bucket, sd 8; the slabs take 1.5 x the mean.  112 = + 6 sd: uniform keys are never turned away, and
+    // what is turned away (1.75 x and more in some bucket) would certainly not have fitted
+    const int over = __syncthreads_or(tid < 256 && s_hist[tid & 255] > 112u);
+    if (tid == 0) __hip_atomic_store(host_report, over ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 constexpr int kSampleWGs = 16;
 enum { kDynMode = 0, kDynLowBits = 4 };   // words of the sort's mode block (work buffer): [4] = bits the finish sorts
 
