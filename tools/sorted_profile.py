@@ -1,6 +1,8 @@
+#!/usr/bin/env python3
+"""Per-kernel times of the large sort on sorted and on uniform keys (64 Mi u32)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oclradixsort_amd import Buffer, DeviceUtils, Pprims
 import oracle
 d = DeviceUtils.allocate(); p = Pprims()
