@@ -81,10 +81,15 @@ struct adlhip_device {
     int tile_variant = -1;    // index into kVariants; -1 = best known per element size
     int rank_mode = 1;        // 1 = lane-ordered DS atomic ranking (needs lds_ordered), 0 = ballot match
     int lds_ordered = 0;      // result of the device self-test at creation
+    int resident_wgs_device = 0;
+    int resident_wgs = 0;     // workgroups of <= 80 KiB LDS / 512 threads that are certainly resident at once (2 per CU); the paths
+                              // whose kernels hold a grid-wide barrier over 256 workgroups are taken only when this is >= 256
     int mid_path = 1;         // 16 Ki < n <= 2 Mi: MSD pass + LDS finish (three launches) instead of per-digit passes
     int mid_skip = 0;         // eligible sorts still to be sent down the per-digit passes after a skewed input (see mid_eligible)
     int mid2_skip = 0;        // keys-only sorts still to take the three-launch form after a slab overflow (see mid_sort_keys)
     int mid_backoff = 32, mid2_backoff = 64;
+    int bin_finish = 1;       // "sort.binfinish": the large keys-only sort finishes its segments with one counting pass + compares
+                              // (1: u64 keys, 2: u32 keys too, 0: the wave-per-segment LSD finish)
     int msd2_path = 1;        // "sort.msd2": the large sort (msd2_sort for keys, msd2s_sort for pairs); 2 = forced (tests)
     int msd2_skip = 0, msd2_backoff = 32;   // sorts the next overflow report keeps off the large sort (x8 each time, reset by a success)
     bool msd2_trusted = false;              // a good report has come in since the last bad one (msd2_decide)
@@ -660,7 +665,10 @@ int launch_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* s
     if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
     // as many workgroups as are resident at once (LDS- or wave-limited), each loops over segments
     const size_t per_cu = std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)32 / (NT / 64)));
-    const uint32_t grid = (uint32_t)std::min<size_t>(num_segments, per_cu * (size_t)d->prop.multiProcessorCount);
+    // slab form (slab.state != nullptr): exactly one workgroup per bucket -- the kernel reads its bucket's count and offset once;
+    // workgroups that are not resident yet simply follow (mid_eligible keeps the form off devices that hold fewer than 256)
+    const uint32_t grid = slab.state ? (uint32_t)num_segments
+                                     : (uint32_t)std::min<size_t>(num_segments, per_cu * (size_t)d->prop.multiProcessorCount);
     return launch(d, sizeof(E) == 4 ? "segment_sort_u32" : "segment_sort_e64", [&] {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, d->stream, in, out, seg_start, (uint32_t)num_segments, (uint32_t)low_bits,
                            dyn, d->d_fault, coop, slab);
@@ -670,7 +678,8 @@ int launch_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* s
 template <typename E, int K, typename S = E, bool SOA = false>
 int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* seg_start, size_t num_segments, int low_bits,
                              const uint32_t* seg_cnt = nullptr, uint32_t in_stride = 0, const uint32_t* gate = nullptr,
-                             const uint32_t* dyn_low_bits = nullptr, uint32_t* out_vals = nullptr)
+                             const uint32_t* dyn_low_bits = nullptr, uint32_t* out_vals = nullptr, const uint32_t* list = nullptr,
+                             const uint32_t* list_cnt = nullptr)
 {
     // a wave's LDS: its tile + 256 counters; waves per workgroup so that a workgroup takes at most ~48 KiB (three per CU)
     constexpr size_t per_wave = sizeof(E) * 64 * K + 256 * 4;
@@ -680,10 +689,27 @@ int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32
     auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES, STEP, RMIN, S, SOA>;
     const size_t lds = (size_t)WAVES * per_wave;
     if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
-    const uint32_t grid = (uint32_t)((num_segments + WAVES - 1) / WAVES);
-    return launch(d, sizeof(E) == 4 ? "segment_sort_wave_u32" : "segment_sort_wave_e64", [&] {
+    // list form (the segments the binning finish handed over -- usually none): a small grid that takes them in turns
+    const size_t slots = list ? std::min<size_t>(num_segments, (size_t)4 * d->prop.multiProcessorCount) : num_segments;
+    const uint32_t grid = (uint32_t)((slots + WAVES - 1) / WAVES);
+    return launch(d, list ? (sizeof(E) == 4 ? "segment_sort_listed_u32" : "segment_sort_listed_e64")
+                          : (sizeof(E) == 4 ? "segment_sort_wave_u32" : "segment_sort_wave_e64"), [&] {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, d->stream, in, out, seg_start, (uint32_t)num_segments,
-                           (uint32_t)low_bits, d->d_fault, seg_cnt, in_stride, gate, dyn_low_bits, out_vals);
+                           (uint32_t)low_bits, d->d_fault, seg_cnt, in_stride, gate, dyn_low_bits, out_vals, list, list_cnt);
+    });
+}
+
+// the binning finish of the large keys-only sort (hybrid_kernels.hpp bin_segment_sort_kernel): one workgroup per segment slab
+template <typename E, typename S, int NT, int K, int BITS>
+int launch_bin_segment_sort(adlhip_device* d, const S* in, E* out, const uint32_t* seg_off, const uint32_t* seg_cnt, uint32_t in_stride,
+                            uint32_t* mode, uint32_t* hard_list)
+{
+    auto kern = adlhip::bin_segment_sort_kernel<E, S, NT, K, BITS>;
+    const size_t lds = align_up(sizeof(S) * NT * K, 16) + ((size_t)(1 << BITS) / 2 + 4) * 4 + (NT / 64 + 4) * 4;
+    if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
+    return launch(d, sizeof(E) == 4 ? "segment_sort_bin_u32" : "segment_sort_bin_u64", [&] {
+        hipLaunchKernelGGL(kern, dim3(65536), dim3(NT), lds, d->stream, in, out, seg_off, seg_cnt, in_stride, (const uint32_t*)mode,
+                           mode + adlhip::kDynHardCnt, hard_list, d->d_fault);
     });
 }
 
@@ -747,6 +773,7 @@ MidLayout mid_layout(size_t n)
 
 bool mid_eligible(const adlhip_device* d, size_t elem_bytes, size_t n, int sort_bits, int max_bits)
 {
+    if (d->resident_wgs < 256) return false;   // the finish's one workgroup per bucket doubles as a 256-workgroup cooperative sort
     return d->sort_algo < 0 && d->mid_path && max_bits == 32 && sort_bits == 32 && d->rank_mode == 1 && d->digit_bits == 8 &&
            d->tile_variant < 0 && n > kSmallMax && n <= (elem_bytes == 4 ? kMidMaxU32 : kMidMaxE64);
 }
@@ -877,7 +904,7 @@ constexpr size_t kMsd2MaxU64 = (size_t(1) << 28) + (size_t(1) << 22);   // mean 
 // the wave-per-segment finish's tiles: 64 * 20, 64 * 40, 64 * 80 elements
 
 struct Msd2Layout {
-    size_t off_mode, off_cnt, off_off, off_coop, off_slab_a, off_slab_b, total;
+    size_t off_mode, off_cnt, off_off, off_hard, off_coop, off_slab_a, off_slab_b, total;
     uint32_t stride_a, stride_b, tiles_per_bucket;
 };
 
@@ -910,7 +937,8 @@ Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
     L.off_mode = 0;
     L.off_cnt = L.off_mode + 256;
     L.off_off = L.off_cnt + 65536 * 4;
-    L.off_coop = align_up(L.off_off + 65537 * 4, 256);                       // safety net: table [256][256] + 256 totals
+    L.off_hard = align_up(L.off_off + 65537 * 4, 256);                       // segments the binning finish hands to the LSD finish
+    L.off_coop = L.off_hard + 65536 * 4;                                     // safety net: table [256][256] + 256 totals
     L.off_slab_a = align_up(L.off_coop + (size_t)256 * 256 * 4 + 1024, 256);
     L.off_slab_b = align_up(L.off_slab_a + (size_t)256 * L.stride_a * elem_bytes, 256);
     L.total = L.off_slab_b + (size_t)65536 * L.stride_b * (elem_bytes == 4 ? 2 : elem_bytes);   // u32 keys: 16-bit second slab
@@ -921,8 +949,9 @@ Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
 bool msd2_eligible(const adlhip_device* d, size_t elem_bytes, size_t n, int sort_bits, int max_bits)
 {
     if (!(d->sort_algo < 0 && d->msd2_path && d->rank_mode == 1 && d->digit_bits == 8 && d->tile_variant < 0)) return false;
+    if (d->resident_wgs < 256) return false;   // the safety net's grid barrier spans 256 workgroups
     if (sort_bits != max_bits || (int)elem_bytes * 8 != max_bits) return false;   // whole keys only; {key, value} pairs: never
-    if (n <= (d->msd2_path == 2 ? kMsd2Min : kMsd2AutoMin)) return false;
+    if (n <= (d->msd2_path >= 2 ? kMsd2Min : kMsd2AutoMin)) return false;
     return n <= (elem_bytes == 4 ? kMsd2MaxU32 : kMsd2MaxU64);
 }
 
@@ -938,7 +967,7 @@ bool msd2_eligible(const adlhip_device* d, size_t elem_bytes, size_t n, int sort
 enum Msd2Choice { kMsd2Skip = 0, kMsd2Use = 1, kMsd2Probe = 2 };
 Msd2Choice msd2_decide(adlhip_device* d)
 {
-    if (d->msd2_path == 2) return kMsd2Use;
+    if (d->msd2_path >= 2) return kMsd2Use;
     if (d->msd2_skip > 0) {
         --d->msd2_skip;
         return kMsd2Skip;
@@ -951,9 +980,11 @@ Msd2Choice msd2_decide(adlhip_device* d)
         d->msd2_backoff = std::min(d->msd2_backoff * 8, 4096);
         return kMsd2Skip;
     }
-    if (report == 1u) {
+    if (report == 1u) {   // a large sort went through
         d->msd2_trusted = true;
         d->msd2_backoff = 32;
+    } else if (report == 3u) {   // the probe saw no obstacle: try the sort, but keep the back-off where it is -- keys that pass the
+        d->msd2_trusted = true;  // probe and still overflow (skew at the scale of single segments) must not cycle for ever
     }
     return d->msd2_trusted ? kMsd2Use : kMsd2Probe;
 }
@@ -1000,7 +1031,7 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     // where the two digits sit is chosen on the device from a sample of the keys (hybrid_kernels.hpp msd2_sample_kernel)
     int rc = launch(d, "msd2_sample", [&] {
         hipLaunchKernelGGL(adlhip::msd2_sample_kernel<E>, dim3(adlhip::kSampleWGs), dim3(64), 0, d->stream, (const E*)data, (uint32_t)n,
-                           sample, flag + 2);
+                           sample, flag + 2, d->d_fault);
     });
     if (rc) return rc;
     adlhip::BucketPass<E> pa;   // pass 1: the input, first digit -> 256 bucket slabs
@@ -1035,6 +1066,20 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     // the finish sorts the bits below the second digit (the offsets kernel has published how many), a wave per segment
     const uint32_t* lowb = mode + adlhip::kDynLowBits;
     using S = typename std::conditional<sizeof(E) == 4, uint16_t, E>::type;   // what pass 2 wrote
+    if (d->bin_finish && (sizeof(E) == 8 || d->bin_finish == 2)) {
+        // one counting pass on the top bits below the digits + whole-key comparisons inside the bins; segments with crowded bins
+        // (keys that are not random down there) go onto a list for the LSD finish right behind it
+        uint32_t* hard = reinterpret_cast<uint32_t*>(wb + L.off_hard);
+        const S* sb = reinterpret_cast<const S*>(slab_b);
+        if (L.stride_b <= kMsd2Stride0) rc = launch_bin_segment_sort<E, S, 256, 6, 11>(d, sb, data, seg_off, seg_cnt, L.stride_b, mode, hard);
+        else if (L.stride_b == 2560) rc = launch_bin_segment_sort<E, S, 256, 10, 12>(d, sb, data, seg_off, seg_cnt, L.stride_b, mode, hard);
+        else rc = launch_bin_segment_sort<E, S, 512, 10, 12>(d, sb, data, seg_off, seg_cnt, L.stride_b, mode, hard);
+        if (rc) return rc;
+        const uint32_t* hc = mode + adlhip::kDynHardCnt;
+        if (L.stride_b <= kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb, nullptr, hard, hc);
+        if (L.stride_b == 2560) return launch_wave_segment_sort<E, 40, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb, nullptr, hard, hc);
+        return launch_wave_segment_sort<E, 80, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb, nullptr, hard, hc);
+    }
     if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
     else if (L.stride_b == kMsd2Stride0) rc = launch_wave_segment_sort<E, kMsd2Stride0 / 64, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
     else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
@@ -1046,7 +1091,8 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
 // ---- the same for {key, value} pairs, STABLE: look-back instead of cursors (hybrid_kernels.hpp msd_lookback_scatter_kernel) --
 constexpr size_t kMsd2sAutoMin = size_t(6) << 20;   // pairs; measured: 4 Mi pairs 0.133 vs 0.102 ms, 8 Mi 0.172 vs 0.183
 constexpr size_t kMsd2sMax = (size_t(1) << 28) + (size_t(1) << 22);
-constexpr uint32_t kMsd2sTile = 8192;               // TileCfg<uint64_t, 8, 512, 16>
+// tile of the look-back passes: TileCfg<uint64_t, 8, 512, 16> = 8192 pairs, TileCfg<uint32_t, 8, 512, 32> = 16384 keys
+constexpr uint32_t msd2s_tile(size_t elem_bytes) { return elem_bytes == 8 ? 8192u : 16384u; }
 
 struct Msd2sLayout {
     size_t off_mode, off_place, off_cnt, off_off, off_coop, off_tickets, off_status_a, off_status_b, off_slab_a, off_slab_b, total;
@@ -1054,9 +1100,10 @@ struct Msd2sLayout {
     size_t status_bytes_a, status_bytes_b;
 };
 
-Msd2sLayout msd2s_layout(size_t n)
+Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8)
 {
     Msd2sLayout L;
+    const uint32_t kMsd2sTile = msd2s_tile(elem_bytes);
     // pieces = chains of pass A = sub-slabs per bucket.  16 = twice the number of XCDs: workgroup i runs on XCD i % 8 and takes
     // chain i % 16, so a chain's tiles stay on ONE XCD -- its status rows and the abutting runs of consecutive tiles meet in
     // that XCD's L2.  Chain counts that break this measured slower although they make pass B's tiles fuller (64 Mi pairs,
@@ -1101,8 +1148,8 @@ Msd2sLayout msd2s_layout(size_t n)
     L.off_status_a = align_up(L.off_tickets + (size_t)L.ticket_words * 4, 256);
     L.off_status_b = L.off_status_a + rows_a_bound * 1024;
     L.off_slab_a = align_up(L.off_status_b + 256 * rows_b_bound * 1024, 256);
-    L.off_slab_b = align_up(L.off_slab_a + 256 * bucket_bound * 8, 256);
-    L.total = L.off_slab_b + (size_t)65536 * L.stride_b * 8;
+    L.off_slab_b = align_up(L.off_slab_a + 256 * bucket_bound * elem_bytes, 256);
+    L.total = L.off_slab_b + (size_t)65536 * L.stride_b * elem_bytes;
     if ((size_t)L.pieces * L.rows_a > rows_a_bound || L.rows_b > rows_b_bound || (size_t)L.pieces * L.stride_a > bucket_bound)
         L.total = 0;   // cannot happen; msd2s_sort refuses
     return L;
@@ -1111,16 +1158,21 @@ Msd2sLayout msd2s_layout(size_t n)
 bool msd2s_eligible(const adlhip_device* d, size_t elem_bytes, size_t n, int sort_bits, int max_bits)
 {
     if (!(d->sort_algo < 0 && d->msd2_path && d->rank_mode == 1 && d->digit_bits == 8 && d->tile_variant < 0)) return false;
+    if (d->resident_wgs < 256) return false;
     if (elem_bytes != 8 || max_bits != 32 || sort_bits != 32) return false;   // {key, value} pairs, whole keys
-    return n > (d->msd2_path == 2 ? kMsd2Min : kMsd2sAutoMin) && n <= kMsd2sMax;
+    return n > (d->msd2_path >= 2 ? kMsd2Min : kMsd2sAutoMin) && n <= kMsd2sMax;
 }
 
 // AoS pairs: data / tmp.  SoA pairs (soa_keys != nullptr): the input and output are the two u32 arrays; data / tmp are unused
 // (the safety net packs the input into the first slab area and sorts it there against the second).
-int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size_t n, uint32_t* soa_keys = nullptr,
+// E = uint64_t: pairs.  E = uint32_t: u32 keys through the same stable passes ("sort.msd2" = 3; the second slab holds their low
+// 16 bits, as in the cursor form).
+template <typename E>
+int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, uint32_t* soa_keys = nullptr,
                uint32_t* soa_vals = nullptr)
 {
-    typedef uint64_t E;
+    constexpr int K = sizeof(E) == 8 ? 16 : 32;
+    constexpr bool k32 = sizeof(E) == 4;
     if (!d->d_msd2) {
         HIPCHK(hipMalloc(&d->d_msd2, (8192 + 65536 + 64) * 4));
         HIPCHK(hipMemsetAsync(d->d_msd2, 0, (8192 + 65536 + 64) * 4, d->stream));
@@ -1129,7 +1181,7 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     uint32_t* flag = d->d_msd2 + 8192 + 65536;
     uint32_t* done = flag + 1;
     uint32_t* bar = flag + 2;
-    const Msd2sLayout L = msd2s_layout(n);
+    const Msd2sLayout L = msd2s_layout(n, sizeof(E));
     if (L.total == 0) return fail("internal: layout bounds of the stable large sort");
     char* wb = reinterpret_cast<char*>(work);
     uint32_t* mode = reinterpret_cast<uint32_t*>(wb + L.off_mode);
@@ -1141,19 +1193,19 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     uint32_t* status_b = reinterpret_cast<uint32_t*>(wb + L.off_status_b);
     E* slab_a = reinterpret_cast<E*>(wb + L.off_slab_a);
     E* slab_b = reinterpret_cast<E*>(wb + L.off_slab_b);
-    using CT = adlhip::TileCfg<E, 8, 512, 16>;
-    static_assert(CT::TILE == (int)kMsd2sTile, "layout and kernel agree on the tile");
-    auto kern = adlhip::msd_lookback_scatter_kernel<E, 512, 16>;
+    using CT = adlhip::TileCfg<E, 8, 512, K>;
+    static_assert(CT::TILE == (int)msd2s_tile(sizeof(E)), "layout and kernel agree on the tile");
+    auto kern = adlhip::msd_lookback_scatter_kernel<E, 512, K>;
     if (ensure_lds(kern, CT::LDS_BYTES)) return ADLHIP_FAILURE;
     // status rows of both passes: zero (one memset; the rows are contiguous)
     HIPCHK(hipMemsetAsync(status_a, 0, (L.off_status_b - L.off_status_a) + L.status_bytes_b, d->stream));
     int rc = launch(d, "msd2s_prep", [&] {
         if (soa_keys)
             hipLaunchKernelGGL(adlhip::msd2s_prep_kernel<uint32_t>, dim3(1), dim3(1024), 0, d->stream, (const uint32_t*)soa_keys,
-                               (uint32_t)n, place, tickets, L.ticket_words, bar);
+                               (uint32_t)n, place, tickets, L.ticket_words, bar, d->d_fault);
         else
             hipLaunchKernelGGL(adlhip::msd2s_prep_kernel<E>, dim3(1), dim3(1024), 0, d->stream, (const E*)data, (uint32_t)n, place, tickets,
-                               L.ticket_words, bar);
+                               L.ticket_words, bar, d->d_fault);
     });
     if (rc) return rc;
     adlhip::LookbackPass<E> pa;
@@ -1161,8 +1213,8 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     pa.flag = flag; pa.fault = d->d_fault; pa.place = place; pa.which_digit = 1; pa.n = (uint32_t)n; pa.chains = L.pieces; pa.pieces = L.pieces;
     pa.rows_per_chain = L.rows_a; pa.slice = L.slice; pa.src_stride = 0; pa.status_a = nullptr; pa.rows_per_chain_a = 0;
     pa.dst_stride = L.stride_a; pa.dst_total = 256u * L.pieces * L.stride_a;
-    pa.soa_keys = soa_keys; pa.soa_vals = soa_vals;
-    rc = launch(d, soa_keys ? "msd2s_pass1_soa" : "msd2s_pass1_kv32", [&] {
+    pa.soa_keys = soa_keys; pa.soa_vals = soa_vals; pa.dst16 = 0;
+    rc = launch(d, k32 ? "msd2s_pass1_u32" : soa_keys ? "msd2s_pass1_soa" : "msd2s_pass1_kv32", [&] {
         hipLaunchKernelGGL(kern, dim3(L.pieces * L.rows_a), dim3(512), CT::LDS_BYTES, d->stream, pa);
     });
     if (rc) return rc;
@@ -1172,7 +1224,8 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     pb.src_stride = L.stride_a; pb.status_a = status_a; pb.rows_per_chain_a = L.rows_a; pb.dst_stride = L.stride_b;
     pb.dst_total = 65536u * L.stride_b;
     pb.soa_keys = nullptr; pb.soa_vals = nullptr;
-    rc = launch(d, soa_keys ? "msd2s_pass2_soa" : "msd2s_pass2_kv32", [&] {
+    pb.dst16 = k32 ? 1 : 0;
+    rc = launch(d, k32 ? "msd2s_pass2_u32" : soa_keys ? "msd2s_pass2_soa" : "msd2s_pass2_kv32", [&] {
         hipLaunchKernelGGL(kern, dim3(256 * L.rows_b), dim3(512), CT::LDS_BYTES, d->stream, pb);
     });
     if (rc) return rc;
@@ -1186,6 +1239,13 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     });
     if (rc) return rc;
     const uint32_t* lowb = mode + adlhip::kDynLowBits;
+    if constexpr (k32) {   // 16-bit second slab
+        typedef uint16_t S;
+        if (L.stride_b == 1280) return launch_wave_segment_sort<E, 20, S>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
+        if (L.stride_b == kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
+        if (L.stride_b == 2560) return launch_wave_segment_sort<E, 40, S>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
+        return launch_wave_segment_sort<E, 80, S>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
+    } else {
     if (soa_keys) {   // the finish writes keys and values to their own arrays
         E* ko = reinterpret_cast<E*>(soa_keys);
         if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
@@ -1199,6 +1259,7 @@ int msd2s_sort(adlhip_device* d, uint64_t* data, uint64_t* tmp, void* work, size
     else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
     else rc = launch_wave_segment_sort<E, 80>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
     return rc;
+    }
 }
 
 size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)
@@ -1210,7 +1271,8 @@ size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)
     else b = onesweep_layout(d, n, max_passes_for(d, 64), buf_tile<AosBuf<uint64_t>>(d, n)).total;   // as onesweep_sort<Buf>()
     const size_t c = n <= kMidMaxU32 ? mid_layout(n).total : mid_layout(kMidMaxU32).total;   // mid-size sort (monotone in n)
     size_t e = 0;   // large keys-only sort: slabs behind the one-sweep layout (monotone in n up to its limit)
-    if (elem_kind == ADLHIP_ELEM_U32 && n > kMsd2Min) e = msd2_layout(std::min(n, kMsd2MaxU32), 4).total;
+    if (elem_kind == ADLHIP_ELEM_U32 && n > kMsd2Min)
+        e = std::max(msd2_layout(std::min(n, kMsd2MaxU32), 4).total, msd2s_layout(std::min(n, kMsd2sMax), 4).total);
     if (elem_kind == ADLHIP_ELEM_U64 && n > kMsd2Min) e = msd2_layout(std::min(n, kMsd2MaxU64), 8).total;
     if ((elem_kind == ADLHIP_ELEM_KV32 || elem_kind == ADLHIP_ELEM_SOA32) && n > kMsd2Min) e = msd2s_layout(std::min(n, kMsd2sMax)).total;
     return std::max(std::max(a, b), std::max(c, e));
@@ -1280,13 +1342,16 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
     }
     if (msd2_eligible(d, sizeof(E), n, sort_bits, max_bits)) {
         const Msd2Choice c = msd2_decide(d);
+        if constexpr (sizeof(E) == 4) {
+            if (c == kMsd2Use && d->msd2_path == 3 && n <= kMsd2sMax) return msd2s_sort<E>(d, data, tmp, work, n);   // stable passes
+        }
         if (c == kMsd2Use) return msd2_sort<E>(d, data, tmp, work, n);
         if (c == kMsd2Probe && msd2_probe(d, data, sizeof(E), max_bits, n)) return ADLHIP_FAILURE;
     }
     if constexpr (sizeof(E) == 8) {
         if (msd2s_eligible(d, sizeof(E), n, sort_bits, max_bits)) {
             const Msd2Choice c = msd2_decide(d);
-            if (c == kMsd2Use) return msd2s_sort(d, data, tmp, work, n);
+            if (c == kMsd2Use) return msd2s_sort<uint64_t>(d, data, tmp, work, n);
             if (c == kMsd2Probe && msd2_probe(d, data, 8, 32, n)) return ADLHIP_FAILURE;
         }
     }
@@ -1457,6 +1522,23 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         uint32_t mism = 1;
         d->lds_ordered = (run_lds_order_selftest(d, 64, &mism) == ADLHIP_SUCCESS && mism == 0) ? 1 : 0;
         d->rank_mode = d->lds_ordered;
+    }
+    {   // how many workgroups of the kernels that hold a grid-wide barrier (the safety nets of the mid-size and large sorts, 256
+        // workgroups each) this device keeps resident at once: asked of the runtime for the two largest of them
+        int a = 0, b = 0;
+        using CS = adlhip::TileCfg<uint32_t, 8, 512, 32>;
+        using CO = adlhip::TileCfg<uint64_t, 8, 256, 16>;
+        const size_t lds_s = std::max<size_t>(sizeof(uint32_t) * 512 * 32 + (size_t)8 * 256 * 6 + 64, CS::LDS_BYTES);
+        auto ks = adlhip::segment_sort_kernel<uint32_t, 512, 32, 8>;
+        auto ko = adlhip::msd2_offsets_kernel<uint64_t>;
+        if (ensure_lds(ks, lds_s) == ADLHIP_SUCCESS &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(ks), 512, lds_s) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(ko), 256, CO::LDS_BYTES) == hipSuccess)
+            d->resident_wgs = std::min(a, b) * d->prop.multiProcessorCount;
+        else
+            d->resident_wgs = d->prop.multiProcessorCount;   // one per CU at least
+        d->resident_wgs_device = d->resident_wgs;
+        (void)hipGetLastError();
     }
     if (const char* a = getenv("ADLHIP_SORT_ALGO")) { int v = atoi(a); if (v >= -1 && v <= 1) d->sort_algo = v; }
     if (const char* t = getenv("ADLHIP_SORT_TILE")) { int v = atoi(t); if (v >= -1 && v < kNumVariants) d->tile_variant = v; }
@@ -1768,7 +1850,7 @@ int adlhip_radix_sort_soa32(adlhip_device* d, uint32_t* keys, uint32_t* vals, ui
         return fail("sort buffers must be 16-byte aligned");
     if (msd2s_eligible(d, 8, n, sort_bits, 32)) {
         const Msd2Choice c = msd2_decide(d);
-        if (c == kMsd2Use) return msd2s_sort(d, nullptr, nullptr, work, n, keys, vals);
+        if (c == kMsd2Use) return msd2s_sort<uint64_t>(d, nullptr, nullptr, work, n, keys, vals);
         if (c == kMsd2Probe && msd2_probe(d, keys, 4, 32, n)) return ADLHIP_FAILURE;
     }
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
@@ -1906,8 +1988,16 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
         if (value < 0 || value > 3) return fail("sort.mid must be 0 (off), 1 (on), 2 (keys: always the two-launch form) or 3 (always the three-launch form)");
         d->mid_path = value;
     } else if (!strcmp(name, "sort.msd2")) {
-        if (value < 0 || value > 2) return fail("sort.msd2 must be 0 (off), 1 (on) or 2 (always, whatever the hints say)");
+        if (value < 0 || value > 3) return fail("sort.msd2 must be 0 (off), 1 (on), 2 (always, whatever the hints say) or 3 (always, u32 keys through the stable passes too)");
         d->msd2_path = value;
+    } else if (!strcmp(name, "sort.binfinish")) {
+        if (value < 0 || value > 2) return fail("sort.binfinish must be 0 (LSD finish), 1 (binning finish for u64 keys) or 2 (for u32 keys too)");
+        d->bin_finish = value;
+    } else if (!strcmp(name, "debug.resident_wgs")) {
+        // what the paths with a grid-wide barrier (the safety nets) and the one-workgroup-per-bucket finish may count on;
+        // 0 = ask the device again.  Tests use it to stand in for a small partition.
+        if (value < 0) return fail("debug.resident_wgs must be >= 0");
+        d->resident_wgs = value ? value : d->resident_wgs_device;
     } else if (!strcmp(name, "sort.rank")) {
         if (value != 0 && value != 1) return fail("sort.rank must be 0 or 1");
         if (value == 1 && !d->lds_ordered) return fail("sort.rank = 1 needs lane-ordered DS atomics; the device self-test failed");
@@ -1931,6 +2021,8 @@ int adlhip_get_param(adlhip_device* d, const char* name, int* value)
     else if (!strcmp(name, "sort.rank")) *value = d->rank_mode;
     else if (!strcmp(name, "sort.mid")) *value = d->mid_path;
     else if (!strcmp(name, "sort.msd2")) *value = d->msd2_path;
+    else if (!strcmp(name, "sort.binfinish")) *value = d->bin_finish;
+    else if (!strcmp(name, "debug.resident_wgs")) *value = d->resident_wgs;
     else if (!strcmp(name, "sort.lds_ordered")) *value = d->lds_ordered;
     else if (!strcmp(name, "profile")) *value = d->profile;
     else return fail("unknown parameter '%s'", name);

@@ -508,7 +508,9 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
                                                                         const uint32_t* __restrict__ seg_cnt, uint32_t in_stride,
                                                                         const uint32_t* __restrict__ gate,
                                                                         const uint32_t* __restrict__ dyn_low_bits,
-                                                                        uint32_t* out_vals /* SOA: out = the key array */)
+                                                                        uint32_t* out_vals /* SOA: out = the key array */,
+                                                                        const uint32_t* __restrict__ list /* or nullptr */,
+                                                                        const uint32_t* __restrict__ list_cnt)
 {
     if (gate && *gate != 0u) return;
     if (dyn_low_bits) low_bits = *dyn_low_bits;
@@ -519,31 +521,172 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
     unsigned char* mine = smem + (size_t)w * (sizeof(E) * CAP + 256 * 4);
     E* __restrict__ buf = reinterpret_cast<E*>(mine);
     uint32_t* __restrict__ cnt = reinterpret_cast<uint32_t*>(mine + sizeof(E) * CAP);
+    auto one = [&](uint32_t seg) {
+        const uint32_t begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_start[seg]);
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seg_cnt ? seg_cnt[seg] : seg_start[seg + 1] - begin));
+        if (m == 0u) return;
+        if (m > (uint32_t)CAP || low_bits > 8u * (uint32_t)sizeof(E)) {   // never sort wrongly in silence
+            if (lane == 0) atomicOr(fault + 1, 0x40000u);
+            return;
+        }
+        if constexpr (SOA) {
+            const E* src = in + (size_t)seg * in_stride;
+            wave_sort_dispatch<E, RMIN, K, STEP, true, E, true>((int)((m + 63u) >> 6), src,
+                                                                reinterpret_cast<E*>(reinterpret_cast<uint32_t*>(out) + begin),
+                                                                out_vals + begin, m, lane, buf, cnt, low_bits, E(0));
+        } else if constexpr (sizeof(S) == sizeof(E)) {
+            const E* src = in + (seg_cnt ? (size_t)seg * in_stride : (size_t)begin);
+            wave_sort_dispatch<E, RMIN, K, STEP, true, E, false>((int)((m + 63u) >> 6), src, out + begin, nullptr, m, lane, buf, cnt,
+                                                                 low_bits, E(0));
+        } else {
+            // slab form with 16-bit elements: the key's bits above low_bits are (sampled prefix, segment number)
+            const S* src = reinterpret_cast<const S*>(in) + (size_t)seg * in_stride;
+            const E hi = (E)(((dyn_low_bits[1] << 16) | seg) << low_bits);
+            wave_sort_dispatch<E, RMIN, K, STEP, true, S, false>((int)((m + 63u) >> 6), src, out + begin, nullptr, m, lane, buf, cnt,
+                                                                 low_bits, hi);
+        }
+    };
     // wave-uniform values, said so (derived from threadIdx they count as divergent)
-    const uint32_t seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)WAVES + (uint32_t)w));
-    if (seg >= num_segments) return;
-    const uint32_t begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_start[seg]);
-    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seg_cnt ? seg_cnt[seg] : seg_start[seg + 1] - begin));
-    if (m == 0u) return;
-    if (m > (uint32_t)CAP || low_bits > 8u * (uint32_t)sizeof(E)) {   // never sort wrongly in silence
-        if (lane == 0) atomicOr(fault + 1, 0x40000u);
+    const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)WAVES + (uint32_t)w));
+    if (list == nullptr) {
+        if (slot < num_segments) one(slot);
         return;
     }
-    if constexpr (SOA) {
-        const E* src = in + (size_t)seg * in_stride;
-        wave_sort_dispatch<E, RMIN, K, STEP, true, E, true>((int)((m + 63u) >> 6), src,
-                                                            reinterpret_cast<E*>(reinterpret_cast<uint32_t*>(out) + begin),
-                                                            out_vals + begin, m, lane, buf, cnt, low_bits, E(0));
-    } else if constexpr (sizeof(S) == sizeof(E)) {
-        const E* src = in + (seg_cnt ? (size_t)seg * in_stride : (size_t)begin);
-        wave_sort_dispatch<E, RMIN, K, STEP, true, E, false>((int)((m + 63u) >> 6), src, out + begin, nullptr, m, lane, buf, cnt,
-                                                             low_bits, E(0));
-    } else {
-        // slab form with 16-bit elements: the key's bits above low_bits are (sampled prefix, segment number)
-        const S* src = reinterpret_cast<const S*>(in) + (size_t)seg * in_stride;
-        const E hi = (E)(((dyn_low_bits[1] << 16) | seg) << low_bits);
-        wave_sort_dispatch<E, RMIN, K, STEP, true, S, false>((int)((m + 63u) >> 6), src, out + begin, nullptr, m, lane, buf, cnt,
-                                                             low_bits, hi);
+    // list form: the segments bin_segment_sort_kernel handed over (a few, or none at all), taken in turns by a small grid
+    const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)*list_cnt);
+    for (uint32_t i = slot; i < nl && i < num_segments; i += gridDim.x * (uint32_t)WAVES)
+        one((uint32_t)__builtin_amdgcn_readfirstlane((int)list[i]));
+}
+
+// ------------------------------------------------------------------------------------------
+// Finish of the large KEYS-ONLY sort, one workgroup per segment, ONE counting pass whatever the number of low bits:
+// the keys of a segment share everything above their low `low_bits` bits and are otherwise as good as random (that is what
+// the two MSD digits above them leave), so binning them on the TOP `BITS` of the low bits -- about one bin per key --
+// almost sorts the segment: what remains are the few keys that share a bin, and those are put in order by comparing whole
+// keys.  Equal keys are indistinguishable, so nothing has to be stable: all waves share one set of counters and a key's
+// rank inside its bin is the value its (returning) counting atomic handed back.
+//   load -> returning DS add on the key's bin (two 16-bit counters per word) | barrier | counters -> bin starts (block scan,
+//   in place) | barrier | key -> LDS at start[bin] + rank | barrier | every position p: the key there goes to
+//   out[start[bin] + number of keys of its bin that are smaller (or equal and earlier)] -- bins of one key: out[p].
+// LDS operations per key: ~7 (the wave-per-segment finish: 4 per 8-bit pass, 24 for the 48 low bits of u64 keys), and a
+// segment of 4096 u64 keys is worked on by 8 waves instead of one wave holding 80 rows (three WAVES per CU).
+// A segment whose bins fill unevenly (more than kBinLimit keys in a bin: keys that are not random below the digits --
+// duplicates, constant bit fields) is not finished here: its number goes onto a list and wave_segment_sort_kernel in its
+// list form (stable LSD passes, any keys) does it right behind this kernel.
+// S = stored element: E, or uint16_t for the 16-bit second slab of u32 keys (hi restores the bits above).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kBinLimit = 16;
+// words of the sort's mode block (work buffer): [0] = 1: the safety net has sorted, the finish returns at once; [4] = bits the
+// finish sorts, [5] = the keys' sampled prefix; [8] = number of listed segments (cleared by the offsets kernel)
+enum { kDynMode = 0, kDynLowBits = 4, kDynHardCnt = 8 };
+
+template <typename E, typename S, int NT, int K, int BITS>
+__global__ __launch_bounds__(NT) void bin_segment_sort_kernel(const S* __restrict__ in, E* __restrict__ out,
+                                                              const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_cnt,
+                                                              uint32_t in_stride, const uint32_t* __restrict__ mode,
+                                                              uint32_t* __restrict__ hard_cnt, uint32_t* __restrict__ hard_list,
+                                                              uint32_t* fault)
+{
+    if (mode[kDynMode] != 0u) return;   // the safety net has sorted instead
+    constexpr int CAP = NT * K;
+    constexpr int BINS = 1 << BITS;
+    constexpr int WORDS = BINS / 2;     // two 16-bit counters per word: bin b = half (b & 1) of word b >> 1
+    constexpr int WPT = WORDS / NT;     // words per thread in the scan
+    static_assert(WORDS % NT == 0 && WPT >= 1, "whole words per thread");
+    static_assert(CAP < 65536, "16-bit positions");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    S* __restrict__ s_buf = reinterpret_cast<S*>(smem);
+    uint32_t* __restrict__ s_cnt = reinterpret_cast<uint32_t*>(smem + ((sizeof(S) * CAP + 15) & ~(size_t)15));   // [WORDS + 4]
+    uint16_t* __restrict__ s_start = reinterpret_cast<uint16_t*>(s_cnt);                                           // [BINS + 1]
+    uint32_t* __restrict__ s_wsum = s_cnt + WORDS + 4;
+    const int tid = (int)threadIdx.x;
+    const uint32_t seg = blockIdx.x;
+    const uint32_t m = seg_cnt[seg];
+    if (m == 0u) return;
+    if (m > (uint32_t)CAP) {   // never sort wrongly in silence
+        if (tid == 0) atomicOr(fault + 1, 0x40000u);
+        return;
+    }
+    const uint32_t low_bits = mode[kDynLowBits];
+    const int sh = low_bits > (uint32_t)BITS ? (int)low_bits - BITS : 0;
+    const uint32_t dmask = low_bits >= (uint32_t)BITS ? (uint32_t)BINS - 1u : (1u << low_bits) - 1u;
+    auto bin_of = [&](S x) -> uint32_t { return (uint32_t)(x >> sh) & dmask; };
+    const S* __restrict__ src = in + (size_t)seg * in_stride;
+    if (low_bits == 0u) {   // nothing left to sort (the digits above covered every bit that varies): the segment only moves
+        E* __restrict__ dst0 = out + seg_off[seg];
+        E hi0 = E(0);
+        if constexpr (sizeof(S) != sizeof(E)) hi0 = (E)((mode[kDynLowBits + 1] << 16) | seg);
+        for (uint32_t i = (uint32_t)tid; i < m; i += (uint32_t)NT) dst0[i] = (E)src[i] | hi0;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) s_cnt[tid + i * NT] = 0u;
+    S e[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if ((uint32_t)(j * NT + tid) < m) e[j] = src[j * NT + tid];
+    __syncthreads();
+    uint32_t rk[K];
+    bool hard = false;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        if ((uint32_t)(j * NT + tid) < m) {
+            const uint32_t b = bin_of(e[j]);
+            const uint32_t hs = (b & 1u) << 4;
+            const uint32_t old = __hip_atomic_fetch_add(&s_cnt[b >> 1], 1u << hs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            rk[j] = (old >> hs) & 0xffffu;
+            hard |= rk[j] >= kBinLimit;
+        }
+    }
+    if (__syncthreads_or(hard)) {   // (the barrier: every count is final)
+        if (tid == 0) hard_list[__hip_atomic_fetch_add(hard_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = seg;
+        return;
+    }
+    {   // counts -> bin starts, in place: thread t owns words [t * WPT, (t + 1) * WPT)
+        uint32_t wv[WPT];
+        uint32_t sum = 0u;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            wv[i] = s_cnt[tid * WPT + i];
+            sum += (wv[i] & 0xffffu) + (wv[i] >> 16);
+        }
+        uint32_t run = block_excl_scan_u32<NT>(sum, s_wsum, nullptr);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const uint32_t lo = run;
+            run += wv[i] & 0xffffu;
+            const uint32_t hi = run;
+            run += wv[i] >> 16;
+            s_cnt[tid * WPT + i] = lo | (hi << 16);
+        }
+        if (tid == NT - 1) s_cnt[WORDS] = run;   // start[BINS] = m
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if ((uint32_t)(j * NT + tid) < m) s_buf[(uint32_t)s_start[bin_of(e[j])] + rk[j]] = e[j];
+    __syncthreads();
+    E hi_bits = E(0);
+    if constexpr (sizeof(S) != sizeof(E)) hi_bits = (E)(((mode[kDynLowBits + 1] << 16) | seg) << low_bits);
+    E* __restrict__ dst = out + seg_off[seg];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const uint32_t p = (uint32_t)(j * NT + tid);
+        if (p < m) {
+            const S x = s_buf[p];
+            const uint32_t b = bin_of(x);
+            const uint32_t lo = s_start[b], hi = s_start[b + 1];
+            uint32_t f = p;
+            if (hi - lo > 1u) {
+                uint32_t c = 0u;
+                for (uint32_t q = lo; q < hi; ++q) {
+                    const S y = s_buf[q];
+                    c += (y < x || (y == x && q < p)) ? 1u : 0u;
+                }
+                f = lo + c;
+            }
+            dst[f] = (E)x | hi_bits;
+        }
     }
 }
 
@@ -660,17 +803,20 @@ __global__ __launch_bounds__(1024) void msd2_probe_kernel(const E* __restrict__ 
     // mean 64 samples per bucket, sd 8; the slabs take 1.5 x the mean.  112 = + 6 sd: uniform keys are never turned away, and
     // what is turned away (1.75 x and more in some bucket) would certainly not have fitted
     const int over = __syncthreads_or(tid < 256 && s_hist[tid & 255] > 112u);
-    if (tid == 0) __hip_atomic_store(host_report, over ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // 3 = "the probe sees no obstacle" -- not the same as a sort that went through (1): only that resets the host's back-off
+    if (tid == 0) __hip_atomic_store(host_report, over ? 2u : 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 constexpr int kSampleWGs = 16;
-enum { kDynMode = 0, kDynLowBits = 4 };   // words of the sort's mode block (work buffer): [4] = bits the finish sorts
 
 template <typename E>
-__global__ __launch_bounds__(64) void msd2_sample_kernel(const E* __restrict__ src, uint32_t n, uint32_t* sample, uint32_t* bar)
+__global__ __launch_bounds__(64) void msd2_sample_kernel(const E* __restrict__ src, uint32_t n, uint32_t* sample, uint32_t* bar,
+                                                         uint32_t* fault)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0)   // the safety net's grid-barrier counter (used, if at all, in the offsets kernel)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // the safety net's grid-barrier counter (used, if at all, in the offsets kernel)
         __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fault[0] = 0u;   // the live fault word: the first kernel of every sort clears it (include/adlhip.h)
+    }
     const unsigned long long k = (unsigned long long)(blockIdx.x * 64u + threadIdx.x);
     const unsigned long long v = (unsigned long long)src[(size_t)(k * (unsigned long long)n / (unsigned long long)(kSampleWGs * 64))];
     unsigned long long o = v, a = v;
@@ -896,6 +1042,7 @@ __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, 
         __hip_atomic_store(cursors_a + 32 * t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == 0) {
             *mode = overflow ? 1u : 0u;   // the finish returns at once when it is set
+            mode[kDynHardCnt] = 0u;
             seg_off[65536] = n;
             if (sample) {   // the finish sorts the bits below the second digit; the sample words go back to or = 0 / and = ~0
                 mode[kDynLowBits] = (uint32_t)(msd2_placement(sample).top - 16);
@@ -943,11 +1090,15 @@ struct StablePlace {   // written by msd2s_prep_kernel
 // one workgroup: sample 1024 keys -> digit placement; clear the tickets of both passes
 template <typename E>
 __global__ __launch_bounds__(1024) void msd2s_prep_kernel(const E* __restrict__ src, uint32_t n, StablePlace* __restrict__ place,
-                                                           uint32_t* __restrict__ tickets, uint32_t ticket_words, uint32_t* bar)
+                                                           uint32_t* __restrict__ tickets, uint32_t ticket_words, uint32_t* bar,
+                                                           uint32_t* fault)
 {
     __shared__ uint32_t s_or[16], s_and[16];
     const int tid = (int)threadIdx.x;
-    if (tid == 0) __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the safety net's grid-barrier counter
+    if (tid == 0) {
+        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the safety net's grid-barrier counter
+        fault[0] = 0u;   // the live fault word: the first kernel of every sort clears it (the look-back's waiters poll it)
+    }
     for (uint32_t i = (uint32_t)tid; i < ticket_words; i += 1024u) tickets[i] = 0u;
     const uint32_t v = (uint32_t)src[(size_t)((unsigned long long)tid * n / 1024ull)];   // the key is the low dword
     uint32_t o = v, a = v;
@@ -998,6 +1149,8 @@ struct LookbackPass {
     uint32_t dst_total;
     const uint32_t* soa_keys;     // pass A of an SoA sort: the input is two u32 arrays (src unused), packed to {key, value} on load
     const uint32_t* soa_vals;
+    int dst16;                    // pass B of u32 keys: the destination slabs hold uint16_t -- a segment's keys share everything above
+                                  // their low 16 bits (BucketPass::dst16)
 };
 
 template <typename E, int NT, int K>
@@ -1096,13 +1249,15 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
     const uint32_t wbase = (uint32_t)(w * 64 * K + lane);
     E e[K];
     const uint32_t lin = a.which_digit == 1 ? base : s_misc[3];   // index of the tile's first element if it is one stretch
-    if (a.soa_keys) {
-        const int rem = (int)valid - (int)wbase;
-        const uint32_t* __restrict__ kp = a.soa_keys + (size_t)lin + wbase;
-        const uint32_t* __restrict__ vp = a.soa_vals + (size_t)lin + wbase;
+    if (sizeof(E) == 8 && a.soa_keys) {
+        if constexpr (sizeof(E) == 8) {
+            const int rem = (int)valid - (int)wbase;
+            const uint32_t* __restrict__ kp = a.soa_keys + (size_t)lin + wbase;
+            const uint32_t* __restrict__ vp = a.soa_vals + (size_t)lin + wbase;
 #pragma unroll
-        for (int j = 0; j < K; ++j)
-            e[j] = (j * 64 < rem) ? ((E)kp[j * 64] | ((E)vp[j * 64] << 32)) : ~E(0);
+            for (int j = 0; j < K; ++j)
+                e[j] = (j * 64 < rem) ? ((E)kp[j * 64] | ((E)vp[j * 64] << 32)) : ~E(0);
+        }
     } else if (lin != 0xffffffffu) {
         const typename IO::Cursor p = io.cursor((size_t)lin + wbase);
         if (valid == (uint32_t)C::TILE) {
@@ -1226,9 +1381,24 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
         if (end4.z > a.dst_stride) in4.z = 0u;
         if (end4.w > a.dst_stride) in4.w = 0u;
         const u32x4 go = sl * a.dst_stride + in4 - toff4;
-        *reinterpret_cast<u32x4*>(s_goff + 4 * lane) = scaled ? go * (uint32_t)IO::kStoreScale : go;
+        *reinterpret_cast<u32x4*>(s_goff + 4 * lane) = (scaled && !a.dst16) ? go * (uint32_t)IO::kStoreScale : go;
     }
     __syncthreads();
+    if constexpr (sizeof(E) == 4) {
+        if (a.dst16) {   // one 2-byte store per key
+            uint16_t* __restrict__ d16 = reinterpret_cast<uint16_t*>(a.dst);
+#pragma unroll 8
+            for (int i = 0; i < K; ++i) {
+                const uint32_t pos = (uint32_t)(tid + i * NT);
+                if (pos < valid) {
+                    const E v = s_elems[pos];
+                    const uint32_t g = s_goff[digit_of<8>(v, start_bit)] + pos;
+                    if (g < a.dst_total) d16[g] = (uint16_t)v;
+                }
+            }
+            return;
+        }
+    }
     write_out_tile<IO, 8, NT, K, ADLHIP_WRITE_UNROLL>(io, s_elems, s_goff, valid, a.dst_total, start_bit, scaled);
 }
 
@@ -1281,6 +1451,8 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
     if (s_misc[2] == gridDim.x - 1u && t == 0) {
         *mode = overflow ? 1u : 0u;
         mode[kDynLowBits] = place->low_bits;
+        mode[kDynLowBits + 1] = place->prefix;   // for the finish of a 16-bit second slab
+        mode[kDynHardCnt] = 0u;
         seg_off[65536] = n;
         __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1289,17 +1461,21 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
     if (overflow) {   // `bar` is zero here: msd2s_prep_kernel, the first launch of every sort, clears it
         __syncthreads();
         uint32_t target = 0u;
-        if (soa_keys) {   // SoA input: pack it into `data` (here: the first slab area), sort that, unpack
-            for (size_t i = (size_t)blockIdx.x * 256u + (size_t)t; i < n; i += (size_t)gridDim.x * 256u)
-                data[i] = (E)soa_keys[i] | ((E)soa_vals[i] << 32);
-            if (!grid_barrier(bar, target, gridDim.x, fault)) return;
+        if constexpr (sizeof(E) == 8) {
+            if (soa_keys) {   // SoA input: pack it into `data` (here: the first slab area), sort that, unpack
+                for (size_t i = (size_t)blockIdx.x * 256u + (size_t)t; i < n; i += (size_t)gridDim.x * 256u)
+                    data[i] = (E)soa_keys[i] | ((E)soa_vals[i] << 32);
+                if (!grid_barrier(bar, target, gridDim.x, fault)) return;
+            }
         }
         coop_lsd_sort<E, 256, 16>(data, tmp, n, ctable, ctable + 256 * 256, bar, fault, smem, 32, target);
-        if (soa_keys) {   // the sort's last phase ends with a grid barrier: `data` is complete
-            for (size_t i = (size_t)blockIdx.x * 256u + (size_t)t; i < n; i += (size_t)gridDim.x * 256u) {
-                const E x = data[i];
-                soa_keys[i] = (uint32_t)x;
-                soa_vals[i] = (uint32_t)(x >> 32);
+        if constexpr (sizeof(E) == 8) {
+            if (soa_keys) {   // the sort's last phase ends with a grid barrier: `data` is complete
+                for (size_t i = (size_t)blockIdx.x * 256u + (size_t)t; i < n; i += (size_t)gridDim.x * 256u) {
+                    const E x = data[i];
+                    soa_keys[i] = (uint32_t)x;
+                    soa_vals[i] = (uint32_t)(x >> 32);
+                }
             }
         }
     }

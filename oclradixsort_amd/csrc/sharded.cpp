@@ -18,6 +18,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 extern "C" void adlhip_set_last_error(const char* text);   // adlhip.hip: the calling thread's error text
@@ -249,13 +250,24 @@ int adlhip_group_create(const int* device_indices, int num_devices, adlhip_group
     for (int r = 0; r < num_devices; ++r) {
         RankState& s = g->rank[(size_t)r];
         s.device_idx = devs[(size_t)r];
+        // every step records what it acquired before the next one runs, so that the destroy below accounts for exactly what
+        // exists (it refuses a device whose live bytes it cannot explain) and the first error's text survives it
         void* t = nullptr;
-        if (adlhip_device_create(s.device_idx, &s.dev) || adlhip_malloc(s.dev, 256 * 4, &t) ||
-            hipHostMalloc(reinterpret_cast<void**>(&s.h_totals), 256 * 4) != hipSuccess) {
-            adlhip_group_destroy(g);
-            return ADLHIP_FAILURE;
+        bool ok = adlhip_device_create(s.device_idx, &s.dev) == ADLHIP_SUCCESS;
+        if (ok) {
+            ok = adlhip_malloc(s.dev, 256 * 4, &t) == ADLHIP_SUCCESS;
+            if (ok) s.d_totals = static_cast<uint32_t*>(t);
         }
-        s.d_totals = static_cast<uint32_t*>(t);
+        if (ok && hipHostMalloc(reinterpret_cast<void**>(&s.h_totals), 256 * 4) != hipSuccess) {
+            s.h_totals = nullptr;
+            gfail("group: hipHostMalloc of the totals staging failed");
+            ok = false;
+        }
+        if (!ok) {
+            const std::string why = adlhip_last_error();
+            adlhip_group_destroy(g);
+            return gfail("%s", why.c_str());
+        }
     }
     ncclResult_t st = nc->CommInitAll(g->comm.data(), num_devices, devs.data());
     if (st != ncclSuccess) {
