@@ -686,14 +686,26 @@ int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32
     constexpr int WAVES = per_wave <= 6144 ? 8   /* eight waves with the 7 KiB of the 1536-element tile measured slower */ : per_wave <= 12288 ? 4 : per_wave <= 24576 ? 2 : 1;
     constexpr int STEP = K <= 40 ? 2 : 4;        // row-count bodies: every 2 rows, every 4 for the largest tile
     constexpr int RMIN = K <= 24 ? 2 : K / 2;    // the tiles beyond 24 rows exist for segments that need them
-    auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES, STEP, RMIN, S, SOA>;
     const size_t lds = (size_t)WAVES * per_wave;
+    if (list) {
+        if constexpr (!SOA) {
+            auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES, STEP, RMIN, S, SOA, true>;
+            if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
+            // list form (the segments the binning finish handed over -- usually none): a small grid that takes them in turns
+            const size_t slots = std::min<size_t>(num_segments, (size_t)4 * d->prop.multiProcessorCount);
+            const uint32_t grid = (uint32_t)((slots + WAVES - 1) / WAVES);
+            return launch(d, sizeof(E) == 4 ? "segment_sort_listed_u32" : "segment_sort_listed_e64", [&] {
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, d->stream, in, out, seg_start, (uint32_t)num_segments,
+                                   (uint32_t)low_bits, d->d_fault, seg_cnt, in_stride, gate, dyn_low_bits, out_vals, list, list_cnt);
+            });
+        } else {
+            return fail("internal: no list form for SoA");
+        }
+    }
+    auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES, STEP, RMIN, S, SOA, false>;
     if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
-    // list form (the segments the binning finish handed over -- usually none): a small grid that takes them in turns
-    const size_t slots = list ? std::min<size_t>(num_segments, (size_t)4 * d->prop.multiProcessorCount) : num_segments;
-    const uint32_t grid = (uint32_t)((slots + WAVES - 1) / WAVES);
-    return launch(d, list ? (sizeof(E) == 4 ? "segment_sort_listed_u32" : "segment_sort_listed_e64")
-                          : (sizeof(E) == 4 ? "segment_sort_wave_u32" : "segment_sort_wave_e64"), [&] {
+    const uint32_t grid = (uint32_t)((num_segments + WAVES - 1) / WAVES);
+    return launch(d, sizeof(E) == 4 ? "segment_sort_wave_u32" : "segment_sort_wave_e64", [&] {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, d->stream, in, out, seg_start, (uint32_t)num_segments,
                            (uint32_t)low_bits, d->d_fault, seg_cnt, in_stride, gate, dyn_low_bits, out_vals, list, list_cnt);
     });
@@ -705,10 +717,14 @@ int launch_bin_segment_sort(adlhip_device* d, const S* in, E* out, const uint32_
                             uint32_t* mode, uint32_t* hard_list)
 {
     auto kern = adlhip::bin_segment_sort_kernel<E, S, NT, K, BITS>;
-    const size_t lds = align_up(sizeof(S) * NT * K, 16) + ((size_t)(1 << BITS) / 2 + 4) * 4 + (NT / 64 + 4) * 4;
+    const size_t lds = align_up(sizeof(S) * NT * K, 16) + ((size_t)(1 << BITS) / 2) * 4 + (2 * NT / 64 + 4) * 4;
     if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
+    // one workgroup per segment.  (The kernel can loop -- a grid of resident workgroups that take segments in turns and request the
+    // next one's keys early -- but measured slower: 256 Mi u64 keys 1.02 vs 0.89 ms, 64 Mi 0.33 vs 0.26; a workgroup that leaves
+    // hands its LDS to the next one while its stores drain.)
+    const uint32_t grid = 65536u;
     return launch(d, sizeof(E) == 4 ? "segment_sort_bin_u32" : "segment_sort_bin_u64", [&] {
-        hipLaunchKernelGGL(kern, dim3(65536), dim3(NT), lds, d->stream, in, out, seg_off, seg_cnt, in_stride, (const uint32_t*)mode,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, d->stream, in, out, seg_off, seg_cnt, in_stride, 65536u, (const uint32_t*)mode,
                            mode + adlhip::kDynHardCnt, hard_list, d->d_fault);
     });
 }
@@ -945,16 +961,6 @@ Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
     return L;
 }
 
-// elem_bytes 4: u32 keys, sort_bits 32; elem_bytes 8 with max_bits 64: u64 keys, sort_bits 64
-bool msd2_eligible(const adlhip_device* d, size_t elem_bytes, size_t n, int sort_bits, int max_bits)
-{
-    if (!(d->sort_algo < 0 && d->msd2_path && d->rank_mode == 1 && d->digit_bits == 8 && d->tile_variant < 0)) return false;
-    if (d->resident_wgs < 256) return false;   // the safety net's grid barrier spans 256 workgroups
-    if (sort_bits != max_bits || (int)elem_bytes * 8 != max_bits) return false;   // whole keys only; {key, value} pairs: never
-    if (n <= (d->msd2_path >= 2 ? kMsd2Min : kMsd2AutoMin)) return false;
-    return n <= (elem_bytes == 4 ? kMsd2MaxU32 : kMsd2MaxU64);
-}
-
 // Host-side policy.  The kernels report into pinned memory what happened (1 = the keys fitted the slabs, 2 = they did not);
 // the host reads that word at the next call, without synchronising.
 //   * a handle that has no good report yet -- a fresh one, or one whose back-off has just run out -- does not risk the safety
@@ -1001,6 +1007,11 @@ int msd2_probe(adlhip_device* d, const void* keys, size_t elem_bytes, int key_bi
                                key_bits, d->h_fault + 11);
     });
 }
+
+template <typename E, typename S, bool SOA = false>
+int launch_large_finish(adlhip_device* d, const E* slab_b, E* out, uint32_t* out_vals, uint32_t* seg_off, uint32_t* seg_cnt, uint32_t stride_b,
+                        uint32_t* mode, uint32_t* hard, int low_bits_max, bool bin);
+bool use_bin_finish(const adlhip_device* d, size_t elem_bytes, bool key64, size_t n, bool whole_keys);
 
 template <typename E>
 int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
@@ -1063,29 +1074,11 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
                            seg_cnt, seg_off, mode, d->h_fault + 11, (uint32_t)n, sample, data, tmp, ctable, d->d_fault, KEY_BITS);
     });
     if (rc) return rc;
-    // the finish sorts the bits below the second digit (the offsets kernel has published how many), a wave per segment
-    const uint32_t* lowb = mode + adlhip::kDynLowBits;
+    // the finish sorts the bits below the second digit (the offsets kernel has published how many)
     using S = typename std::conditional<sizeof(E) == 4, uint16_t, E>::type;   // what pass 2 wrote
-    if (d->bin_finish && (sizeof(E) == 8 || d->bin_finish == 2)) {
-        // one counting pass on the top bits below the digits + whole-key comparisons inside the bins; segments with crowded bins
-        // (keys that are not random down there) go onto a list for the LSD finish right behind it
-        uint32_t* hard = reinterpret_cast<uint32_t*>(wb + L.off_hard);
-        const S* sb = reinterpret_cast<const S*>(slab_b);
-        if (L.stride_b <= kMsd2Stride0) rc = launch_bin_segment_sort<E, S, 256, 6, 11>(d, sb, data, seg_off, seg_cnt, L.stride_b, mode, hard);
-        else if (L.stride_b == 2560) rc = launch_bin_segment_sort<E, S, 256, 10, 12>(d, sb, data, seg_off, seg_cnt, L.stride_b, mode, hard);
-        else rc = launch_bin_segment_sort<E, S, 512, 10, 12>(d, sb, data, seg_off, seg_cnt, L.stride_b, mode, hard);
-        if (rc) return rc;
-        const uint32_t* hc = mode + adlhip::kDynHardCnt;
-        if (L.stride_b <= kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb, nullptr, hard, hc);
-        if (L.stride_b == 2560) return launch_wave_segment_sort<E, 40, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb, nullptr, hard, hc);
-        return launch_wave_segment_sort<E, 80, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb, nullptr, hard, hc);
-    }
-    if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
-    else if (L.stride_b == kMsd2Stride0) rc = launch_wave_segment_sort<E, kMsd2Stride0 / 64, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
-    else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
-    else rc = launch_wave_segment_sort<E, 80, S>(d, slab_b, data, seg_off, 65536, KEY_BITS - 16, seg_cnt, L.stride_b, mode, lowb);
-    if (rc) return rc;
-    return rc;
+    uint32_t* hard = reinterpret_cast<uint32_t*>(wb + L.off_hard);
+    return launch_large_finish<E, S>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, mode, hard, KEY_BITS - 16,
+                                     use_bin_finish(d, sizeof(E), sizeof(E) == 8, n, true));
 }
 
 // ---- the same for {key, value} pairs, STABLE: look-back instead of cursors (hybrid_kernels.hpp msd_lookback_scatter_kernel) --
@@ -1095,7 +1088,7 @@ constexpr size_t kMsd2sMax = (size_t(1) << 28) + (size_t(1) << 22);
 constexpr uint32_t msd2s_tile(size_t elem_bytes) { return elem_bytes == 8 ? 8192u : 16384u; }
 
 struct Msd2sLayout {
-    size_t off_mode, off_place, off_cnt, off_off, off_coop, off_tickets, off_status_a, off_status_b, off_slab_a, off_slab_b, total;
+    size_t off_mode, off_place, off_cnt, off_off, off_hard, off_coop, off_tickets, off_status_a, off_status_b, off_slab_a, off_slab_b, total;
     uint32_t pieces, slice, rows_a, rows_b, stride_a, stride_b, ticket_words;
     size_t status_bytes_a, status_bytes_b;
 };
@@ -1135,7 +1128,8 @@ Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8)
     L.off_place = 128;
     L.off_cnt = 256;
     L.off_off = L.off_cnt + 65536 * 4;
-    L.off_coop = align_up(L.off_off + 65537 * 4, 256);
+    L.off_hard = align_up(L.off_off + 65537 * 4, 256);
+    L.off_coop = L.off_hard + 65536 * 4;
     L.off_tickets = align_up(L.off_coop + (size_t)256 * 256 * 4 + 1024, 256);
     // the regions are sized by bounds that do not depend on `pieces` and grow with n, so that the scratch for n suffices
     // for every smaller n (adlhip_radix_sort_scratch_bytes): sub-slabs of a bucket together <= n/256 + 16 * (head-room),
@@ -1155,24 +1149,79 @@ Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8)
     return L;
 }
 
-bool msd2s_eligible(const adlhip_device* d, size_t elem_bytes, size_t n, int sort_bits, int max_bits)
+// Which sorts take the large sort, and in which form.  keys: the element is the key (u32 / u64 keys), else {key, value} pairs.
+//   whole u32 keys                      -> cursor passes + 16-bit second slab (msd2_sort)      ["sort.msd2" = 3: stable passes]
+//   whole u64 keys, 32 Mi keys and more -> stable passes + binning finish (msd2s_sort)          ["sort.msd2" = 4: cursor passes,
+//   whole u64 keys below                -> cursor passes (msd2_sort)                             3: stable passes, at every size]
+//   pairs; partial sortBits (>= 16)     -> stable passes + LSD finish (msd2s_sort)
+enum LargeForm { kLargeNone = 0, kLargeCursor, kLargeStable };
+LargeForm large_sort_form(const adlhip_device* d, size_t elem_bytes, bool keys, size_t n, int sort_bits, int max_bits)
 {
-    if (!(d->sort_algo < 0 && d->msd2_path && d->rank_mode == 1 && d->digit_bits == 8 && d->tile_variant < 0)) return false;
-    if (d->resident_wgs < 256) return false;
-    if (elem_bytes != 8 || max_bits != 32 || sort_bits != 32) return false;   // {key, value} pairs, whole keys
-    return n > (d->msd2_path >= 2 ? kMsd2Min : kMsd2sAutoMin) && n <= kMsd2sMax;
+    if (!(d->sort_algo < 0 && d->msd2_path && d->rank_mode == 1 && d->digit_bits == 8 && d->tile_variant < 0)) return kLargeNone;
+    if (d->resident_wgs < 256) return kLargeNone;   // the safety net's grid barrier spans 256 workgroups
+    if (sort_bits < 16) return kLargeNone;          // two 8-bit digits must fit inside the sorted bits
+    const bool forced = d->msd2_path >= 2;
+    const bool whole = sort_bits == max_bits;
+    if (!keys) return n > (forced ? kMsd2Min : kMsd2sAutoMin) && n <= kMsd2sMax ? kLargeStable : kLargeNone;
+    if (n <= (forced ? kMsd2Min : kMsd2AutoMin)) return kLargeNone;
+    // whole u64 keys: the stable passes win from ~32 Mi keys (256 Mi: 2.93 vs 3.13 ms, 64 Mi: 0.850 vs 0.872), the cursor passes with
+    // their smaller fixed cost below (16 Mi: 0.288 vs 0.318 ms; profiles/r3_u64_stable_vs_cursor.txt)
+    const bool cursor = whole && (elem_bytes == 4 ? d->msd2_path != 3
+                                                  : (d->msd2_path == 4 || (d->msd2_path < 3 && n < (size_t(32) << 20))));
+    if (cursor) return n <= (elem_bytes == 4 ? kMsd2MaxU32 : kMsd2MaxU64) ? kLargeCursor : kLargeNone;
+    return n <= kMsd2sMax ? kLargeStable : kLargeNone;
 }
 
-// AoS pairs: data / tmp.  SoA pairs (soa_keys != nullptr): the input and output are the two u32 arrays; data / tmp are unused
-// (the safety net packs the input into the first slab area and sorts it there against the second).
-// E = uint64_t: pairs.  E = uint32_t: u32 keys through the same stable passes ("sort.msd2" = 3; the second slab holds their low
-// 16 bits, as in the cursor form).
-template <typename E>
-int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, uint32_t* soa_keys = nullptr,
+// The finish of either large sort: the binning finish (whole u64 keys from ~24 Mi up: one counting pass + compares, then the
+// LSD finish's list form for what it handed over) or the wave-per-segment LSD finish.  S = what the second slab holds.
+template <typename E, typename S, bool SOA>
+int launch_large_finish(adlhip_device* d, const E* slab_b, E* out, uint32_t* out_vals, uint32_t* seg_off, uint32_t* seg_cnt, uint32_t stride_b,
+                        uint32_t* mode, uint32_t* hard, int low_bits_max, bool bin)
+{
+    const uint32_t* lowb = mode + adlhip::kDynLowBits;
+    if constexpr (!SOA) {
+        if (bin) {
+            const S* sb = reinterpret_cast<const S*>(slab_b);
+            int rc;
+            if (stride_b <= kMsd2Stride0) rc = launch_bin_segment_sort<E, S, 256, 6, 11>(d, sb, out, seg_off, seg_cnt, stride_b, mode, hard);
+            else if (stride_b == 2560) rc = launch_bin_segment_sort<E, S, 256, 10, 12>(d, sb, out, seg_off, seg_cnt, stride_b, mode, hard);
+            else rc = launch_bin_segment_sort<E, S, 512, 10, 12>(d, sb, out, seg_off, seg_cnt, stride_b, mode, hard);
+            if (rc) return rc;
+            const uint32_t* hc = mode + adlhip::kDynHardCnt;
+            if (stride_b <= kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc);
+            if (stride_b == 2560) return launch_wave_segment_sort<E, 40, S>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc);
+            return launch_wave_segment_sort<E, 80, S>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc);
+        }
+    }
+    if (stride_b == 1280) return launch_wave_segment_sort<E, 20, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
+    if (stride_b == kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
+    if (stride_b == 2560) return launch_wave_segment_sort<E, 40, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
+    return launch_wave_segment_sort<E, 80, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
+}
+
+// whole u64 keys: the binning finish pays from a mean segment of ~384 keys (16 Mi keys: 0.144 vs 0.148 ms, 4 Mi: 0.116 vs 0.098,
+// 64 Mi: 0.263 vs 0.406, profiles/r3_bin_finish.txt)
+bool use_bin_finish(const adlhip_device* d, size_t elem_bytes, bool key64, size_t n, bool whole_keys)
+{
+    if (!whole_keys || !d->bin_finish) return false;
+    if (d->bin_finish == 2) return elem_bytes == 4 || key64;   // forced (tests, A/B): any size, u32 keys too
+    return elem_bytes == 8 && key64 && n >= (size_t(24) << 20);
+}
+
+// The stable large sort.  E / KEY64: uint64_t / false = {key, value} pairs (AoS: data / tmp; SoA: soa_keys != nullptr, the input and
+// output are the two u32 arrays, data / tmp are unused -- the safety net packs the input into the first slab area and sorts it
+// there against the second); uint64_t / true = u64 keys; uint32_t / false = u32 keys (whole keys: the second slab holds their low
+// 16 bits, as in the cursor form).  sort_bits < key bits (Pprims.cpp:357, a multiple of 4, at least 16 here): only the low sort_bits
+// bits of a key count -- the digits are placed inside them, everything is stable, so keys that agree there keep their input order
+// as the reference's LSD passes would leave them.
+template <typename E, bool KEY64>
+int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort_bits, uint32_t* soa_keys = nullptr,
                uint32_t* soa_vals = nullptr)
 {
     constexpr int K = sizeof(E) == 8 ? 16 : 32;
     constexpr bool k32 = sizeof(E) == 4;
+    constexpr int KEY_BITS = KEY64 ? 64 : 32;
+    const bool whole = sort_bits == KEY_BITS;
     if (!d->d_msd2) {
         HIPCHK(hipMalloc(&d->d_msd2, (8192 + 65536 + 64) * 4));
         HIPCHK(hipMemsetAsync(d->d_msd2, 0, (8192 + 65536 + 64) * 4, d->stream));
@@ -1188,6 +1237,7 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, uint32_t
     adlhip::StablePlace* place = reinterpret_cast<adlhip::StablePlace*>(wb + L.off_place);
     uint32_t* seg_cnt = reinterpret_cast<uint32_t*>(wb + L.off_cnt);
     uint32_t* seg_off = reinterpret_cast<uint32_t*>(wb + L.off_off);
+    uint32_t* hard = reinterpret_cast<uint32_t*>(wb + L.off_hard);
     uint32_t* tickets = reinterpret_cast<uint32_t*>(wb + L.off_tickets);
     uint32_t* status_a = reinterpret_cast<uint32_t*>(wb + L.off_status_a);
     uint32_t* status_b = reinterpret_cast<uint32_t*>(wb + L.off_status_b);
@@ -1195,17 +1245,17 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, uint32_t
     E* slab_b = reinterpret_cast<E*>(wb + L.off_slab_b);
     using CT = adlhip::TileCfg<E, 8, 512, K>;
     static_assert(CT::TILE == (int)msd2s_tile(sizeof(E)), "layout and kernel agree on the tile");
-    auto kern = adlhip::msd_lookback_scatter_kernel<E, 512, K>;
+    auto kern = adlhip::msd_lookback_scatter_kernel<E, 512, K, KEY64>;
     if (ensure_lds(kern, CT::LDS_BYTES)) return ADLHIP_FAILURE;
     // status rows of both passes: zero (one memset; the rows are contiguous)
     HIPCHK(hipMemsetAsync(status_a, 0, (L.off_status_b - L.off_status_a) + L.status_bytes_b, d->stream));
     int rc = launch(d, "msd2s_prep", [&] {
         if (soa_keys)
-            hipLaunchKernelGGL(adlhip::msd2s_prep_kernel<uint32_t>, dim3(1), dim3(1024), 0, d->stream, (const uint32_t*)soa_keys,
-                               (uint32_t)n, place, tickets, L.ticket_words, bar, d->d_fault);
+            hipLaunchKernelGGL((adlhip::msd2s_prep_kernel<uint32_t, false>), dim3(1), dim3(1024), 0, d->stream, (const uint32_t*)soa_keys,
+                               (uint32_t)n, place, tickets, L.ticket_words, bar, d->d_fault, (uint32_t)sort_bits);
         else
-            hipLaunchKernelGGL(adlhip::msd2s_prep_kernel<E>, dim3(1), dim3(1024), 0, d->stream, (const E*)data, (uint32_t)n, place, tickets,
-                               L.ticket_words, bar, d->d_fault);
+            hipLaunchKernelGGL((adlhip::msd2s_prep_kernel<E, KEY64>), dim3(1), dim3(1024), 0, d->stream, (const E*)data, (uint32_t)n, place,
+                               tickets, L.ticket_words, bar, d->d_fault, (uint32_t)sort_bits);
     });
     if (rc) return rc;
     adlhip::LookbackPass<E> pa;
@@ -1214,7 +1264,7 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, uint32_t
     pa.rows_per_chain = L.rows_a; pa.slice = L.slice; pa.src_stride = 0; pa.status_a = nullptr; pa.rows_per_chain_a = 0;
     pa.dst_stride = L.stride_a; pa.dst_total = 256u * L.pieces * L.stride_a;
     pa.soa_keys = soa_keys; pa.soa_vals = soa_vals; pa.dst16 = 0;
-    rc = launch(d, k32 ? "msd2s_pass1_u32" : soa_keys ? "msd2s_pass1_soa" : "msd2s_pass1_kv32", [&] {
+    rc = launch(d, k32 ? "msd2s_pass1_u32" : KEY64 ? "msd2s_pass1_u64" : soa_keys ? "msd2s_pass1_soa" : "msd2s_pass1_kv32", [&] {
         hipLaunchKernelGGL(kern, dim3(L.pieces * L.rows_a), dim3(512), CT::LDS_BYTES, d->stream, pa);
     });
     if (rc) return rc;
@@ -1224,8 +1274,9 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, uint32_t
     pb.src_stride = L.stride_a; pb.status_a = status_a; pb.rows_per_chain_a = L.rows_a; pb.dst_stride = L.stride_b;
     pb.dst_total = 65536u * L.stride_b;
     pb.soa_keys = nullptr; pb.soa_vals = nullptr;
-    pb.dst16 = k32 ? 1 : 0;
-    rc = launch(d, k32 ? "msd2s_pass2_u32" : soa_keys ? "msd2s_pass2_soa" : "msd2s_pass2_kv32", [&] {
+    const bool slab16 = k32 && whole;   // whole u32 keys: a segment's keys share everything above their low 16 bits
+    pb.dst16 = slab16 ? 1 : 0;
+    rc = launch(d, k32 ? "msd2s_pass2_u32" : KEY64 ? "msd2s_pass2_u64" : soa_keys ? "msd2s_pass2_soa" : "msd2s_pass2_kv32", [&] {
         hipLaunchKernelGGL(kern, dim3(256 * L.rows_b), dim3(512), CT::LDS_BYTES, d->stream, pb);
     });
     if (rc) return rc;
@@ -1238,27 +1289,16 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, uint32_t
                            soa_keys ? slab_a : data, soa_keys ? slab_b : tmp, ctable, d->d_fault, soa_keys, soa_vals);
     });
     if (rc) return rc;
-    const uint32_t* lowb = mode + adlhip::kDynLowBits;
-    if constexpr (k32) {   // 16-bit second slab
-        typedef uint16_t S;
-        if (L.stride_b == 1280) return launch_wave_segment_sort<E, 20, S>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
-        if (L.stride_b == kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
-        if (L.stride_b == 2560) return launch_wave_segment_sort<E, 40, S>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
-        return launch_wave_segment_sort<E, 80, S>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
+    const int low_max = sort_bits - 16;
+    const bool bin = use_bin_finish(d, sizeof(E), KEY64, n, whole);
+    if constexpr (k32) {
+        if (slab16) return launch_large_finish<E, uint16_t>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, mode, hard, low_max, bin);
+        return launch_large_finish<E, E>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, mode, hard, low_max, false);
     } else {
-    if (soa_keys) {   // the finish writes keys and values to their own arrays
-        E* ko = reinterpret_cast<E*>(soa_keys);
-        if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
-        else if (L.stride_b == kMsd2Stride0) rc = launch_wave_segment_sort<E, kMsd2Stride0 / 64, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
-        else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
-        else rc = launch_wave_segment_sort<E, 80, E, true>(d, slab_b, ko, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb, soa_vals);
-        return rc;
-    }
-    if (L.stride_b == 1280) rc = launch_wave_segment_sort<E, 20>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
-    else if (L.stride_b == kMsd2Stride0) rc = launch_wave_segment_sort<E, kMsd2Stride0 / 64>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
-    else if (L.stride_b == 2560) rc = launch_wave_segment_sort<E, 40>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
-    else rc = launch_wave_segment_sort<E, 80>(d, slab_b, data, seg_off, 65536, 16, seg_cnt, L.stride_b, mode, lowb);
-    return rc;
+        if (soa_keys)   // the finish writes keys and values to their own arrays
+            return launch_large_finish<E, E, true>(d, slab_b, reinterpret_cast<E*>(soa_keys), soa_vals, seg_off, seg_cnt, L.stride_b, mode, hard,
+                                                   low_max, false);
+        return launch_large_finish<E, E>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, mode, hard, low_max, bin);
     }
 }
 
@@ -1273,7 +1313,8 @@ size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)
     size_t e = 0;   // large keys-only sort: slabs behind the one-sweep layout (monotone in n up to its limit)
     if (elem_kind == ADLHIP_ELEM_U32 && n > kMsd2Min)
         e = std::max(msd2_layout(std::min(n, kMsd2MaxU32), 4).total, msd2s_layout(std::min(n, kMsd2sMax), 4).total);
-    if (elem_kind == ADLHIP_ELEM_U64 && n > kMsd2Min) e = msd2_layout(std::min(n, kMsd2MaxU64), 8).total;
+    if (elem_kind == ADLHIP_ELEM_U64 && n > kMsd2Min)
+        e = std::max(msd2_layout(std::min(n, kMsd2MaxU64), 8).total, msd2s_layout(std::min(n, kMsd2sMax), 8).total);
     if ((elem_kind == ADLHIP_ELEM_KV32 || elem_kind == ADLHIP_ELEM_SOA32) && n > kMsd2Min) e = msd2s_layout(std::min(n, kMsd2sMax)).total;
     return std::max(std::max(a, b), std::max(c, e));
 }
@@ -1340,20 +1381,20 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
         }
         if (form == 3) return mid_sort<E>(d, data, tmp, work, n);         // three launches
     }
-    if (msd2_eligible(d, sizeof(E), n, sort_bits, max_bits)) {
+    const bool keys = (int)sizeof(E) * 8 == max_bits;
+    const LargeForm form = large_sort_form(d, sizeof(E), keys, n, sort_bits, max_bits);
+    if (form != kLargeNone) {
         const Msd2Choice c = msd2_decide(d);
-        if constexpr (sizeof(E) == 4) {
-            if (c == kMsd2Use && d->msd2_path == 3 && n <= kMsd2sMax) return msd2s_sort<E>(d, data, tmp, work, n);   // stable passes
+        if (c == kMsd2Use) {
+            if (form == kLargeCursor) return msd2_sort<E>(d, data, tmp, work, n);
+            if constexpr (sizeof(E) == 4) {
+                return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits);
+            } else {
+                if (keys) return msd2s_sort<E, true>(d, data, tmp, work, n, sort_bits);
+                return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits);
+            }
         }
-        if (c == kMsd2Use) return msd2_sort<E>(d, data, tmp, work, n);
-        if (c == kMsd2Probe && msd2_probe(d, data, sizeof(E), max_bits, n)) return ADLHIP_FAILURE;
-    }
-    if constexpr (sizeof(E) == 8) {
-        if (msd2s_eligible(d, sizeof(E), n, sort_bits, max_bits)) {
-            const Msd2Choice c = msd2_decide(d);
-            if (c == kMsd2Use) return msd2s_sort<uint64_t>(d, data, tmp, work, n);
-            if (c == kMsd2Probe && msd2_probe(d, data, 8, 32, n)) return ADLHIP_FAILURE;
-        }
+        if (c == kMsd2Probe && msd2_probe(d, data, sizeof(E), sort_bits, n)) return ADLHIP_FAILURE;
     }
     return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, n, plan);
 }
@@ -1848,10 +1889,10 @@ int adlhip_radix_sort_soa32(adlhip_device* d, uint32_t* keys, uint32_t* vals, ui
     if (!vals || !tmp_vals) return fail("null value buffer passed to radix sort");
     if ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(tmp_vals)) & 15u)
         return fail("sort buffers must be 16-byte aligned");
-    if (msd2s_eligible(d, 8, n, sort_bits, 32)) {
+    if (large_sort_form(d, 8, false, n, sort_bits, 32) != kLargeNone) {
         const Msd2Choice c = msd2_decide(d);
-        if (c == kMsd2Use) return msd2s_sort<uint64_t>(d, nullptr, nullptr, work, n, keys, vals);
-        if (c == kMsd2Probe && msd2_probe(d, keys, 4, 32, n)) return ADLHIP_FAILURE;
+        if (c == kMsd2Use) return msd2s_sort<uint64_t, false>(d, nullptr, nullptr, work, n, sort_bits, keys, vals);
+        if (c == kMsd2Probe && msd2_probe(d, keys, 4, sort_bits, n)) return ADLHIP_FAILURE;
     }
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
     return run_sort<SoaBuf>(d, SoaBuf{keys, vals}, SoaBuf{tmp_keys, tmp_vals}, work, n, plan);
@@ -1988,10 +2029,12 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
         if (value < 0 || value > 3) return fail("sort.mid must be 0 (off), 1 (on), 2 (keys: always the two-launch form) or 3 (always the three-launch form)");
         d->mid_path = value;
     } else if (!strcmp(name, "sort.msd2")) {
-        if (value < 0 || value > 3) return fail("sort.msd2 must be 0 (off), 1 (on), 2 (always, whatever the hints say) or 3 (always, u32 keys through the stable passes too)");
+        if (value < 0 || value > 4)
+            return fail("sort.msd2 must be 0 (off), 1 (on), 2 (always, whatever the hints say), 3 (always; whole u32 keys through the stable "
+                        "passes too) or 4 (always; whole u64 keys through the cursor passes)");
         d->msd2_path = value;
     } else if (!strcmp(name, "sort.binfinish")) {
-        if (value < 0 || value > 2) return fail("sort.binfinish must be 0 (LSD finish), 1 (binning finish for u64 keys) or 2 (for u32 keys too)");
+        if (value < 0 || value > 2) return fail("sort.binfinish must be 0 (LSD finish), 1 (binning finish for whole u64 keys from 24 Mi keys up) or 2 (always, u32 keys too)");
         d->bin_finish = value;
     } else if (!strcmp(name, "debug.resident_wgs")) {
         // what the paths with a grid-wide barrier (the safety nets) and the one-workgroup-per-bucket finish may count on;

@@ -86,12 +86,16 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
     uint32_t target = target0;   // the barrier counter is zero on entry unless the caller has used it already
     E* src = data;
     E* dst = tmp;
-    for (int sb = 0; sb < key_bits; sb += 8) {   // 32: u32 keys and {key, value} pairs; 64: u64 keys (an even number of passes)
+    // key_bits: 32 (u32 keys, pairs), 64 (u64 keys), or the sortBits of a partial sort (a multiple of 4: the last digit is then 4
+    // bits wide, and an odd number of passes leaves the result in tmp -- copied back, Pprims.cpp:400-403)
+    for (int sb = 0; sb < key_bits; sb += 8) {
+        const bool narrow = key_bits - sb < 8;
+        const uint32_t dm = narrow ? 15u : 255u;
         // ---- count the digits of this workgroup's run of tiles --------------------------------------------------------
         for (int i = tid; i < NW * 256; i += NT) hist[i] = 0u;
         __syncthreads();
         for (uint32_t i = e0 + (uint32_t)tid; i < e1; i += (uint32_t)NT)
-            atomicAdd(&hist[w * 256 + ((uint32_t)(src[i] >> sb) & 255u)], 1u);
+            atomicAdd(&hist[w * 256 + ((uint32_t)(src[i] >> sb) & dm)], 1u);
         __syncthreads();
         if (tid < 256) {
             uint32_t c = 0u;
@@ -122,12 +126,20 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
             for (uint32_t t = t0; t < t1; ++t) {
                 const uint32_t tb = t * (uint32_t)C::TILE;
                 const uint32_t left = n - tb;
-                sort_scatter_tile<AosIO<E>, 8, NT, K, 1>(io, tb, left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE, n, sb, smem,
-                                                         [&](int, uint32_t c) { const uint32_t g = carry; carry += c; return g; });
+                const uint32_t valid = left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE;
+                if (narrow)
+                    sort_scatter_tile<AosIO<E>, 4, NT, K, 1>(io, tb, valid, n, sb, smem,
+                                                             [&](int, uint32_t c) { const uint32_t g = carry; carry += c; return g; });
+                else
+                    sort_scatter_tile<AosIO<E>, 8, NT, K, 1>(io, tb, valid, n, sb, smem,
+                                                             [&](int, uint32_t c) { const uint32_t g = carry; carry += c; return g; });
             }
         }
         if (!grid_barrier(bar, target, wgs, fault)) return;
         E* t = src; src = dst; dst = t;
+    }
+    if (src != data) {   // odd number of passes: the result sits in tmp (the barrier above made it visible)
+        for (size_t i = (size_t)wg * NT + (size_t)tid; i < n; i += (size_t)wgs * NT) data[i] = src[i];
     }
 }
 
@@ -502,14 +514,17 @@ __device__ __forceinline__ void wave_sort_dispatch(int rows, const S* __restrict
     }
 }
 
-template <typename E, int K, int WAVES, int STEP, int RMIN, typename S, bool SOA>
+// LIST: the segments to do are list[0 .. *list_cnt) -- what bin_segment_sort_kernel handed over, usually nothing -- taken in turns
+// by a small grid; otherwise wave i of the grid does segment i.  (One call site of the body per instantiation: with two, the
+// compiler stops inlining the 80-row bodies and the kernel runs three times slower.)
+template <typename E, int K, int WAVES, int STEP, int RMIN, typename S, bool SOA, bool LIST>
 __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* in, E* out, const uint32_t* __restrict__ seg_start,
                                                                         uint32_t num_segments, uint32_t low_bits, uint32_t* fault,
                                                                         const uint32_t* __restrict__ seg_cnt, uint32_t in_stride,
                                                                         const uint32_t* __restrict__ gate,
                                                                         const uint32_t* __restrict__ dyn_low_bits,
                                                                         uint32_t* out_vals /* SOA: out = the key array */,
-                                                                        const uint32_t* __restrict__ list /* or nullptr */,
+                                                                        const uint32_t* __restrict__ list,
                                                                         const uint32_t* __restrict__ list_cnt)
 {
     if (gate && *gate != 0u) return;
@@ -521,13 +536,22 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
     unsigned char* mine = smem + (size_t)w * (sizeof(E) * CAP + 256 * 4);
     E* __restrict__ buf = reinterpret_cast<E*>(mine);
     uint32_t* __restrict__ cnt = reinterpret_cast<uint32_t*>(mine + sizeof(E) * CAP);
-    auto one = [&](uint32_t seg) {
+    // wave-uniform values, said so (derived from threadIdx they count as divergent)
+    uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)WAVES + (uint32_t)w));
+    uint32_t limit = num_segments;
+    if constexpr (LIST) {
+        const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)*list_cnt);
+        limit = nl < num_segments ? nl : num_segments;
+    }
+    for (; slot < limit; slot = LIST ? slot + gridDim.x * (uint32_t)WAVES : limit) {
+        uint32_t seg = slot;
+        if constexpr (LIST) seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[slot]);
         const uint32_t begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_start[seg]);
         const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seg_cnt ? seg_cnt[seg] : seg_start[seg + 1] - begin));
-        if (m == 0u) return;
+        if (m == 0u) continue;
         if (m > (uint32_t)CAP || low_bits > 8u * (uint32_t)sizeof(E)) {   // never sort wrongly in silence
             if (lane == 0) atomicOr(fault + 1, 0x40000u);
-            return;
+            continue;
         }
         if constexpr (SOA) {
             const E* src = in + (size_t)seg * in_stride;
@@ -545,17 +569,7 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
             wave_sort_dispatch<E, RMIN, K, STEP, true, S, false>((int)((m + 63u) >> 6), src, out + begin, nullptr, m, lane, buf, cnt,
                                                                  low_bits, hi);
         }
-    };
-    // wave-uniform values, said so (derived from threadIdx they count as divergent)
-    const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)WAVES + (uint32_t)w));
-    if (list == nullptr) {
-        if (slot < num_segments) one(slot);
-        return;
     }
-    // list form: the segments bin_segment_sort_kernel handed over (a few, or none at all), taken in turns by a small grid
-    const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)*list_cnt);
-    for (uint32_t i = slot; i < nl && i < num_segments; i += gridDim.x * (uint32_t)WAVES)
-        one((uint32_t)__builtin_amdgcn_readfirstlane((int)list[i]));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -576,14 +590,17 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
 // S = stored element: E, or uint16_t for the 16-bit second slab of u32 keys (hi restores the bits above).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kBinLimit = 16;
+// barrier over LDS traffic only: __syncthreads() also waits for every global load and store of the wave (vmcnt(0)), which in a
+// workgroup that loops would serialise the next segment's loads and this segment's stores with the LDS phases
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // words of the sort's mode block (work buffer): [0] = 1: the safety net has sorted, the finish returns at once; [4] = bits the
 // finish sorts, [5] = the keys' sampled prefix; [8] = number of listed segments (cleared by the offsets kernel)
 enum { kDynMode = 0, kDynLowBits = 4, kDynHardCnt = 8 };
 
 template <typename E, typename S, int NT, int K, int BITS>
-__global__ __launch_bounds__(NT) void bin_segment_sort_kernel(const S* __restrict__ in, E* __restrict__ out,
+__global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void bin_segment_sort_kernel(const S* __restrict__ in, E* __restrict__ out,
                                                               const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_cnt,
-                                                              uint32_t in_stride, const uint32_t* __restrict__ mode,
+                                                              uint32_t in_stride, uint32_t num_segments, const uint32_t* __restrict__ mode,
                                                               uint32_t* __restrict__ hard_cnt, uint32_t* __restrict__ hard_list,
                                                               uint32_t* fault)
 {
@@ -591,102 +608,153 @@ __global__ __launch_bounds__(NT) void bin_segment_sort_kernel(const S* __restric
     constexpr int CAP = NT * K;
     constexpr int BINS = 1 << BITS;
     constexpr int WORDS = BINS / 2;     // two 16-bit counters per word: bin b = half (b & 1) of word b >> 1
-    constexpr int WPT = WORDS / NT;     // words per thread in the scan
+    constexpr int WPT = WORDS / NT;     // words per thread in the scan: thread t owns bins [2 * WPT * t, 2 * WPT * (t + 1))
+    constexpr int NW = NT / 64;
     static_assert(WORDS % NT == 0 && WPT >= 1, "whole words per thread");
     static_assert(CAP < 65536, "16-bit positions");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     S* __restrict__ s_buf = reinterpret_cast<S*>(smem);
-    uint32_t* __restrict__ s_cnt = reinterpret_cast<uint32_t*>(smem + ((sizeof(S) * CAP + 15) & ~(size_t)15));   // [WORDS + 4]
-    uint16_t* __restrict__ s_start = reinterpret_cast<uint16_t*>(s_cnt);                                           // [BINS + 1]
-    uint32_t* __restrict__ s_wsum = s_cnt + WORDS + 4;
-    const int tid = (int)threadIdx.x;
-    const uint32_t seg = blockIdx.x;
-    const uint32_t m = seg_cnt[seg];
-    if (m == 0u) return;
-    if (m > (uint32_t)CAP) {   // never sort wrongly in silence
-        if (tid == 0) atomicOr(fault + 1, 0x40000u);
-        return;
-    }
+    uint32_t* __restrict__ s_cnt = reinterpret_cast<uint32_t*>(smem + ((sizeof(S) * CAP + 15) & ~(size_t)15));   // [WORDS]
+    const uint16_t* __restrict__ s_start = reinterpret_cast<const uint16_t*>(s_cnt);                               // [BINS]
+    uint32_t* __restrict__ s_wsum = s_cnt + WORDS;                                                                 // [NW]
+    uint32_t* __restrict__ s_hard = s_wsum + NW;                                                                   // [NW]
+    const int tid0 = (int)threadIdx.x;
+    const int lane = tid0 & 63;
+    const int w = tid0 >> 6;
     const uint32_t low_bits = mode[kDynLowBits];
     const int sh = low_bits > (uint32_t)BITS ? (int)low_bits - BITS : 0;
     const uint32_t dmask = low_bits >= (uint32_t)BITS ? (uint32_t)BINS - 1u : (1u << low_bits) - 1u;
     auto bin_of = [&](S x) -> uint32_t { return (uint32_t)(x >> sh) & dmask; };
-    const S* __restrict__ src = in + (size_t)seg * in_stride;
-    if (low_bits == 0u) {   // nothing left to sort (the digits above covered every bit that varies): the segment only moves
-        E* __restrict__ dst0 = out + seg_off[seg];
-        E hi0 = E(0);
-        if constexpr (sizeof(S) != sizeof(E)) hi0 = (E)((mode[kDynLowBits + 1] << 16) | seg);
-        for (uint32_t i = (uint32_t)tid; i < m; i += (uint32_t)NT) dst0[i] = (E)src[i] | hi0;
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) s_cnt[tid + i * NT] = 0u;
+    uint32_t prefix = 0u;
+    if constexpr (sizeof(S) != sizeof(E)) prefix = mode[kDynLowBits + 1] << 16;
+
+    // persistent: workgroup g takes segments g, g + G, ...; the keys of the next one are requested while this one is sorted
+    uint32_t seg = blockIdx.x;
+    if (seg >= num_segments) return;
+    uint32_t m = seg_cnt[seg];
     S e[K];
+    {
+        const S* __restrict__ src = in + (size_t)seg * in_stride;
 #pragma unroll
-    for (int j = 0; j < K; ++j)
-        if ((uint32_t)(j * NT + tid) < m) e[j] = src[j * NT + tid];
-    __syncthreads();
-    uint32_t rk[K];
-    bool hard = false;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        if ((uint32_t)(j * NT + tid) < m) {
-            const uint32_t b = bin_of(e[j]);
-            const uint32_t hs = (b & 1u) << 4;
-            const uint32_t old = __hip_atomic_fetch_add(&s_cnt[b >> 1], 1u << hs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            rk[j] = (old >> hs) & 0xffffu;
-            hard |= rk[j] >= kBinLimit;
-        }
+        for (int j = 0; j < K; ++j)
+            if ((uint32_t)(j * NT + tid0) < m && m <= (uint32_t)CAP) e[j] = src[j * NT + tid0];
     }
-    if (__syncthreads_or(hard)) {   // (the barrier: every count is final)
-        if (tid == 0) hard_list[__hip_atomic_fetch_add(hard_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = seg;
-        return;
-    }
-    {   // counts -> bin starts, in place: thread t owns words [t * WPT, (t + 1) * WPT)
-        uint32_t wv[WPT];
-        uint32_t sum = 0u;
+    for (;;) {
+        // the thread index, hidden from loop-invariant code motion: hoisted out of the loop, the addresses derived from it took a
+        // hundred registers (167 VGPRs, one workgroup per CU instead of three)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const uint32_t next = seg + gridDim.x;
+        const bool more = next < num_segments;
+        const uint32_t m_next = more ? seg_cnt[next] : 0u;
+        E hi_bits = E(0);
+        if constexpr (sizeof(S) != sizeof(E)) hi_bits = (E)((prefix | seg) << low_bits);
+        E* __restrict__ dst = out + seg_off[seg];
+        auto prefetch_next = [&]() {
+            if (more) {
+                const S* __restrict__ src = in + (size_t)next * in_stride;
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            wv[i] = s_cnt[tid * WPT + i];
-            sum += (wv[i] & 0xffffu) + (wv[i] >> 16);
-        }
-        uint32_t run = block_excl_scan_u32<NT>(sum, s_wsum, nullptr);
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const uint32_t lo = run;
-            run += wv[i] & 0xffffu;
-            const uint32_t hi = run;
-            run += wv[i] >> 16;
-            s_cnt[tid * WPT + i] = lo | (hi << 16);
-        }
-        if (tid == NT - 1) s_cnt[WORDS] = run;   // start[BINS] = m
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < K; ++j)
-        if ((uint32_t)(j * NT + tid) < m) s_buf[(uint32_t)s_start[bin_of(e[j])] + rk[j]] = e[j];
-    __syncthreads();
-    E hi_bits = E(0);
-    if constexpr (sizeof(S) != sizeof(E)) hi_bits = (E)(((mode[kDynLowBits + 1] << 16) | seg) << low_bits);
-    E* __restrict__ dst = out + seg_off[seg];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const uint32_t p = (uint32_t)(j * NT + tid);
-        if (p < m) {
-            const S x = s_buf[p];
-            const uint32_t b = bin_of(x);
-            const uint32_t lo = s_start[b], hi = s_start[b + 1];
-            uint32_t f = p;
-            if (hi - lo > 1u) {
-                uint32_t c = 0u;
-                for (uint32_t q = lo; q < hi; ++q) {
-                    const S y = s_buf[q];
-                    c += (y < x || (y == x && q < p)) ? 1u : 0u;
-                }
-                f = lo + c;
+                for (int j = 0; j < K; ++j)
+                    if ((uint32_t)(j * NT + tid) < m_next && m_next <= (uint32_t)CAP) e[j] = src[j * NT + tid];
             }
-            dst[f] = (E)x | hi_bits;
+        };
+        const bool sortable = m != 0u && m <= (uint32_t)CAP && low_bits != 0u;
+        if (m > (uint32_t)CAP && tid == 0) atomicOr(fault + 1, 0x40000u);   // never sort wrongly in silence
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) s_cnt[tid + i * NT] = 0u;
+        lds_barrier();   // counters are zero; the previous segment's last reads of the tile are done
+        uint32_t rk2[(K + 1) / 2];   // ranks inside the bins, two to a register
+#pragma unroll
+        for (int j = 0; j < (K + 1) / 2; ++j) rk2[j] = 0u;
+        bool hard = false;
+        if (sortable) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if ((uint32_t)(j * NT + tid) < m) {
+                    const uint32_t b = bin_of(e[j]);
+                    const uint32_t hs = (b & 1u) << 4;
+                    const uint32_t old = __hip_atomic_fetch_add(&s_cnt[b >> 1], 1u << hs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t r = (old >> hs) & 0xffffu;
+                    rk2[j >> 1] |= r << (16 * (j & 1));
+                    hard |= r >= kBinLimit;
+                }
+            }
         }
+        if (lane == 0) s_hard[w] = 0u;
+        if (__any(hard) && lane == 0) s_hard[w] = 1u;
+        lds_barrier();   // every count is final
+        bool is_hard = false;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) is_hard |= s_hard[i] != 0u;
+        if (is_hard && tid == 0) hard_list[__hip_atomic_fetch_add(hard_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = seg;
+        if (!is_hard && sortable) {
+            // counts -> bin starts, in place
+            {
+                uint32_t wv[WPT];
+                uint32_t sum = 0u;
+#pragma unroll
+                for (int i = 0; i < WPT; ++i) {
+                    wv[i] = s_cnt[tid * WPT + i];
+                    sum += (wv[i] & 0xffffu) + (wv[i] >> 16);
+                }
+                const uint32_t inc = wave_incl_scan_u32(sum);
+                if (lane == 63) s_wsum[w] = inc;
+                lds_barrier();
+                uint32_t run = inc - sum;
+#pragma unroll
+                for (int i = 0; i < NW; ++i)
+                    if (i < w) run += s_wsum[i];
+#pragma unroll
+                for (int i = 0; i < WPT; ++i) {
+                    const uint32_t c0 = wv[i] & 0xffffu, c1 = wv[i] >> 16;
+                    const uint32_t lo = run;
+                    run += c0;
+                    const uint32_t hi = run;
+                    run += c1;
+                    s_cnt[tid * WPT + i] = lo | (hi << 16);
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if ((uint32_t)(j * NT + tid) < m) s_buf[(uint32_t)s_start[bin_of(e[j])] + ((rk2[j >> 1] >> (16 * (j & 1))) & 0xffffu)] = e[j];
+            prefetch_next();   // the registers are free: the next segment's keys travel while this one is put in order and stored
+            lds_barrier();
+            // every key counts the keys of its bin that come before it (bins of one key: nothing to do) and goes there
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint32_t p = (uint32_t)(j * NT + tid);
+                if (p < m) {
+                    const S x = s_buf[p];
+                    const uint32_t b = bin_of(x);
+                    const uint32_t lo = s_start[b];
+                    const uint32_t hi = b == dmask ? m : (uint32_t)s_start[b + 1u];
+                    uint32_t f = p;
+                    if (hi - lo > 1u) {
+                        uint32_t c = 0u;
+                        for (uint32_t q = lo; q < hi; ++q) {
+                            const S y = s_buf[q];
+                            c += (y < x || (y == x && q < p)) ? 1u : 0u;
+                        }
+                        f = lo + c;
+                    }
+                    dst[f] = (E)x | hi_bits;
+                }
+            }
+            lds_barrier();   // the tile and the bin starts are free for the next segment
+        } else {
+            if (!is_hard && m != 0u && m <= (uint32_t)CAP) {   // nothing left to sort: the segment only moves
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const uint32_t p = (uint32_t)(j * NT + tid);
+                    if (p < m) dst[p] = (E)e[j] | hi_bits;
+                }
+            }
+            prefetch_next();
+        }
+        if (!more) break;
+        seg = next;
+        m = m_next;
     }
 }
 
@@ -1081,27 +1149,39 @@ __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, 
 // Tickets give tile indices in arrival order, so a tile only ever waits for tiles that already run.
 // ------------------------------------------------------------------------------------------
 struct StablePlace {   // written by msd2s_prep_kernel
-    uint32_t top;      // one past the highest key bit in which two sampled keys differ (>= 16)
-    uint32_t prefix;   // key >> top of every key (top < 32)
+    uint32_t top;      // one past the highest key bit (below sort_bits) in which two sampled keys differ (>= 16)
     uint32_t low_bits; // top - 16: what the finish sorts
+    uint32_t sort_bits;
     uint32_t pad;
+    unsigned long long prefix;   // (key & mask(sort_bits)) >> top of every key (top < key bits)
+    unsigned long long kmask;    // mask(sort_bits)
 };
 
-// one workgroup: sample 1024 keys -> digit placement; clear the tickets of both passes
-template <typename E>
+// The key of an element: the whole element (u32 keys; u64 keys: KEY64), or the low dword of a {key, value} pair.
+template <bool KEY64, typename E>
+__device__ __forceinline__ unsigned long long key_of(E e)
+{
+    if constexpr (KEY64) return (unsigned long long)e;
+    else return (unsigned long long)(uint32_t)e;
+}
+
+// one workgroup: sample 1024 keys -> digit placement; clear the tickets of both passes.  Only the low sort_bits bits of a key take
+// part in the sort (Pprims.cpp:357: the passes cover bits [0, sortBits)); the digits are placed inside them.
+template <typename E, bool KEY64>
 __global__ __launch_bounds__(1024) void msd2s_prep_kernel(const E* __restrict__ src, uint32_t n, StablePlace* __restrict__ place,
                                                            uint32_t* __restrict__ tickets, uint32_t ticket_words, uint32_t* bar,
-                                                           uint32_t* fault)
+                                                           uint32_t* fault, uint32_t sort_bits)
 {
-    __shared__ uint32_t s_or[16], s_and[16];
+    __shared__ unsigned long long s_or[16], s_and[16];
     const int tid = (int)threadIdx.x;
     if (tid == 0) {
         __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the safety net's grid-barrier counter
         fault[0] = 0u;   // the live fault word: the first kernel of every sort clears it (the look-back's waiters poll it)
     }
     for (uint32_t i = (uint32_t)tid; i < ticket_words; i += 1024u) tickets[i] = 0u;
-    const uint32_t v = (uint32_t)src[(size_t)((unsigned long long)tid * n / 1024ull)];   // the key is the low dword
-    uint32_t o = v, a = v;
+    const unsigned long long kmask = sort_bits >= 64u ? ~0ull : ((1ull << sort_bits) - 1ull);
+    const unsigned long long v = key_of<KEY64>(src[(size_t)((unsigned long long)tid * n / 1024ull)]) & kmask;
+    unsigned long long o = v, a = v;
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) {
         o |= __shfl_xor(o, sh);
@@ -1117,12 +1197,14 @@ __global__ __launch_bounds__(1024) void msd2s_prep_kernel(const E* __restrict__ 
             o |= s_or[i];
             a &= s_and[i];
         }
-        const uint32_t diff = o ^ a;
-        uint32_t top = diff ? 32u - (uint32_t)__builtin_clz(diff) : 0u;
+        const unsigned long long diff = o ^ a;
+        uint32_t top = diff ? 64u - (uint32_t)__builtin_clzll(diff) : 0u;
         if (top < 16u) top = 16u;
         place->top = top;
-        place->prefix = top < 32u ? (o >> top) : 0u;
+        place->prefix = top < 64u ? (o >> top) : 0ull;
         place->low_bits = top - 16u;
+        place->sort_bits = sort_bits;
+        place->kmask = kmask;
     }
 }
 
@@ -1153,7 +1235,7 @@ struct LookbackPass {
                                   // their low 16 bits (BucketPass::dst16)
 };
 
-template <typename E, int NT, int K>
+template <typename E, int NT, int K, bool KEY64>
 __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E> a)
 {
     using C = TileCfg<E, 8, NT, K>;
@@ -1283,14 +1365,24 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
             e[j] = (j * 64 < rem) ? a.src[(size_t)(q + s_adj[c])] : ~E(0);
         }
     }
-    if (a.which_digit == 1 && a.place->top < 32u) {   // a key outside the sampled range would land in a wrong bucket
-        const uint32_t top = a.place->top, pre = a.place->prefix;
+    if (a.which_digit == 1 && a.place->top < (KEY64 ? 64u : 32u)) {   // a key outside the sampled range would land in a wrong bucket
+        const uint32_t top = a.place->top;
         const int rem = (int)valid - (int)wbase;
-        uint32_t bad = 0u;
+        if constexpr (KEY64) {
+            const unsigned long long pre = a.place->prefix, km = a.place->kmask;
+            unsigned long long bad = 0ull;
 #pragma unroll
-        for (int j = 0; j < K; ++j)
-            if (j * 64 < rem) bad |= ((uint32_t)e[j] >> top) ^ pre;
-        if (bad) __hip_atomic_fetch_or(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = 0; j < K; ++j)
+                if (j * 64 < rem) bad |= (((unsigned long long)e[j] & km) >> top) ^ pre;
+            if (bad) __hip_atomic_fetch_or(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const uint32_t pre = (uint32_t)a.place->prefix, km = (uint32_t)a.place->kmask;
+            uint32_t bad = 0u;
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if (j * 64 < rem) bad |= (((uint32_t)e[j] & km) >> top) ^ pre;
+            if (bad) __hip_atomic_fetch_or(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     // ---- rank ---------------------------------------------------------------------------------------------------------
 #pragma unroll
@@ -1451,7 +1543,7 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
     if (s_misc[2] == gridDim.x - 1u && t == 0) {
         *mode = overflow ? 1u : 0u;
         mode[kDynLowBits] = place->low_bits;
-        mode[kDynLowBits + 1] = place->prefix;   // for the finish of a 16-bit second slab
+        mode[kDynLowBits + 1] = (uint32_t)place->prefix;   // for the finish of a 16-bit second slab
         mode[kDynHardCnt] = 0u;
         seg_off[65536] = n;
         __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1468,7 +1560,7 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
                 if (!grid_barrier(bar, target, gridDim.x, fault)) return;
             }
         }
-        coop_lsd_sort<E, 256, 16>(data, tmp, n, ctable, ctable + 256 * 256, bar, fault, smem, 32, target);
+        coop_lsd_sort<E, 256, 16>(data, tmp, n, ctable, ctable + 256 * 256, bar, fault, smem, (int)place->sort_bits, target);
         if constexpr (sizeof(E) == 8) {
             if (soa_keys) {   // the sort's last phase ends with a grid barrier: `data` is complete
                 for (size_t i = (size_t)blockIdx.x * 256u + (size_t)t; i < n; i += (size_t)gridDim.x * 256u) {

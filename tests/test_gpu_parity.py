@@ -1310,3 +1310,195 @@ def test_large_sort_safety_net_runs_inside_its_offsets_kernel(dev):
         b.release()
         p.close()
 
+
+
+# ---------------------------------------------------------------------------------------------
+# round 3: which kernels a sort ran is asserted, not assumed (the automatic choice depends on hints that arrive
+# asynchronously); config #3 on the path the bench times; partial sortBits, u64 keys and the binning finish on the large sort
+# ---------------------------------------------------------------------------------------------
+def _profiled(dev, fn):
+    """Run fn() with per-launch profiling on; returns (result, {kernel name: (launches, ms)})."""
+    dev.toggleProfiling(True)
+    dev.profile(reset=True)
+    try:
+        out = fn()
+    finally:
+        prof = dev.profile(reset=True)
+        dev.toggleProfiling(False)
+    return out, prof
+
+
+LARGE_PAIRS = {"msd2s_prep", "msd2s_pass1_kv32", "msd2s_pass2_kv32", "msd2s_offsets", "segment_sort_wave_e64"}
+LARGE_U32 = {"msd2_sample", "msd2_pass1_u32", "msd2_pass2_u32", "msd2_offsets", "segment_sort_wave_u32"}
+LARGE_U64_BIN = {"msd2s_prep", "msd2s_pass1_u64", "msd2s_pass2_u64", "msd2s_offsets", "segment_sort_bin_u64", "segment_sort_listed_e64"}
+LARGE_U64_LSD = {"msd2s_prep", "msd2s_pass1_u64", "msd2s_pass2_u64", "msd2s_offsets", "segment_sort_wave_e64"}
+
+
+def test_config3_64m_aos_pairs_on_the_large_path_bit_exact(dev):
+    """BASELINE config #3 (64 Mi {key, value} pairs, AoS) on the path bench.py times -- the stable large sort, forced so that no hint
+    decides -- with 24-bit keys (every key ~4 times: stability shows), bit-exact against the oracle's stable sort; the kernels
+    that ran are the large sort's and nothing else."""
+    n = 1 << 26
+    pairs = oracle.pairs_kv32(n, seed=321) & np.uint64(0xffffffff00ffffff)
+    dev.setParam("sort.msd2", 2)
+    p = Pprims()
+    try:
+        got, prof = _profiled(dev, lambda: gpu_sort_kv(dev, p, pairs))
+        assert set(prof) == LARGE_PAIRS, prof
+        assert np.array_equal(got, oracle.sort_kv32(pairs))
+    finally:
+        dev.setParam("sort.msd2", 1)
+        p.close()
+
+
+def test_size_classes_run_the_kernels_they_claim(dev):
+    """Every size class of the u32 sort, forced where a hint could decide otherwise, with the kernel names asserted."""
+    set_algo(dev, (-1, 8, -1))
+    p = Pprims()
+    try:
+        cases = [
+            (16000, {}, {"small_sort_u32"}),
+            (300007, {"sort.mid": 2}, {"mid_bucket_scatter_u32", "segment_sort_u32"}),
+            (300007, {"sort.mid": 3}, {"mid_prep_u32", "onesweep_u32_8b", "segment_sort_u32"}),
+            ((1 << 22) + 5, {"sort.msd2": 2}, LARGE_U32),
+            ((1 << 22) + 5, {"sort.msd2": 3}, {"msd2s_prep", "msd2s_pass1_u32", "msd2s_pass2_u32", "msd2s_offsets", "segment_sort_wave_u32"}),
+            ((1 << 22) + 5, {"sort.msd2": 0}, {"count_u32_8b", "scan_table", "scatter_u32_8b"}),
+            ((1 << 23) + 5, {"sort.msd2": 0}, {"os_hist_u32", "os_hist_reduce", "os_tables", "onesweep_u32_8b"}),
+        ]
+        for n, knobs, want_names in cases:
+            for k, v in knobs.items():
+                dev.setParam(k, v)
+            try:
+                keys = oracle.keys_u32(n, seed=n & 0xff)
+                got, prof = _profiled(dev, lambda: gpu_sort_u32(dev, p, keys))
+                assert set(prof) == set(want_names), (n, knobs, prof)
+                assert np.array_equal(got, oracle.sort_u32(keys)), (n, knobs)
+            finally:
+                dev.setParam("sort.mid", 1)
+                dev.setParam("sort.msd2", 1)
+    finally:
+        p.close()
+
+
+def test_large_sort_partial_sort_bits(dev):
+    """sortBits < key bits on the large sort (Pprims.cpp:357, :330): the stable form places its digits inside the sorted bits and
+    everything is stable, so keys that agree there keep their input order -- bit-exact against the oracle's partial sort for u32
+    keys, u64 keys and pairs; skewed keys send it to the safety net, whose last digit is then 4 bits wide and whose odd pass
+    counts are copied back (Pprims.cpp:400-403)."""
+    dev.setParam("sort.msd2", 2)
+    p = Pprims()
+    try:
+        n = (1 << 22) + 1234
+        k = oracle.keys_u32(n, seed=41)
+        pr = oracle.pairs_kv32(n, seed=42)
+        k64 = oracle.keys_u64(n, seed=43)
+        for bits in (16, 20, 24, 28):
+            got, prof = _profiled(dev, lambda: gpu_sort_u32(dev, p, k, bits))
+            assert "msd2s_pass1_u32" in prof, (bits, prof)
+            assert np.array_equal(got, oracle.sort_u32_bits(k, bits)), bits
+            got, prof = _profiled(dev, lambda: gpu_sort_kv(dev, p, pr, bits))
+            assert "msd2s_pass1_kv32" in prof, (bits, prof)
+            assert np.array_equal(got, oracle.sort_e64_bits(pr, bits)), bits
+        for bits in (16, 28, 36, 44, 52, 60):
+            got, prof = _profiled(dev, lambda: gpu_sort_u64(dev, p, k64, bits))
+            assert "msd2s_pass1_u64" in prof, (bits, prof)
+            assert np.array_equal(got, oracle.sort_e64_bits(k64, bits)), bits
+        # keys whose sorted bits are skewed: the safety net (odd and even pass counts, a 4-bit last digit)
+        skew = np.where(np.arange(n) % 8 != 0, k & np.uint32(0xfff000ff), k).astype(np.uint32)
+        for bits in (20, 24, 28):
+            assert np.array_equal(gpu_sort_u32(dev, p, skew, bits), oracle.sort_u32_bits(skew, bits)), ("skew", bits)
+        skew64 = np.where(np.arange(n) % 8 != 0, k64 & np.uint64(0xffffffff000000ff), k64).astype(np.uint64)
+        for bits in (36, 44):
+            assert np.array_equal(gpu_sort_u64(dev, p, skew64, bits), oracle.sort_e64_bits(skew64, bits)), ("skew64", bits)
+        skewp = np.where(np.arange(n) % 8 != 0, pr & np.uint64(0xfffffffffff000ff), pr).astype(np.uint64)
+        for bits in (20, 28):
+            assert np.array_equal(gpu_sort_kv(dev, p, skewp, bits), oracle.sort_e64_bits(skewp, bits)), ("skewp", bits)
+        # a 28-bit sort at BASELINE config #2's size
+        big = oracle.keys_u32(1 << 26, seed=44)
+        got, prof = _profiled(dev, lambda: gpu_sort_u32(dev, p, big, 28))
+        assert "msd2s_pass1_u32" in prof, prof
+        assert np.array_equal(got, oracle.sort_u32_bits(big, 28))
+        DeviceUtils.waitForCompletion(dev)
+    finally:
+        dev.setParam("sort.msd2", 1)
+        p.close()
+
+
+def test_u64_keys_stable_passes_binning_finish_and_its_handover(dev):
+    """Whole u64 keys on the large sort: stable MSD passes + the binning finish (one counting pass on the top bits below the
+    digits, whole-key compares inside the bins).  Segments whose bins fill unevenly -- duplicates, constant bit fields -- are
+    handed to the LSD finish's list form.  "sort.binfinish" = 2 takes the binning finish at every size; 0 the LSD finish;
+    "sort.msd2" = 4 the cursor passes.  Bit-exact against the oracle every way."""
+    p = Pprims()
+    try:
+        dev.setParam("sort.msd2", 3)        # the stable passes at every size (the automatic choice takes them from 32 Mi keys up)
+        dev.setParam("sort.binfinish", 2)
+        n = (1 << 23) + 11
+        u = oracle.keys_u64(n, seed=5)
+        cases = {
+            "uniform": u,
+            "top 20 bits unused": u >> np.uint64(20),
+            "values below 2^20 (25 copies of every key: crowded bins)": u >> np.uint64(44),
+            "2^18 distinct values spread over 64 bits": (u >> np.uint64(46)) * np.uint64(0x0000400010000401),
+            "constant low dword": (u & np.uint64(0xffffffff00000000)) | np.uint64(0x9abcdef0),
+            "constant bits 16..47 below the digits": u & np.uint64(0xffff00000000ffff),
+            "low 16 bits only below the digits": (u & np.uint64(0xffff00000000ffff)) | np.uint64(0x0000123456780000),
+            "values below 2^16 (nothing left for the finish)": u >> np.uint64(48),
+            "sorted": np.sort(u),
+            "all equal": np.full(n, 0xdeadbeefcafef00d, dtype=np.uint64),
+        }
+        for nm, k in cases.items():
+            k = k.astype(np.uint64)
+            got, prof = _profiled(dev, lambda: gpu_sort_u64(dev, p, k))
+            assert set(prof) == LARGE_U64_BIN, (nm, prof)
+            assert np.array_equal(got, oracle.sort_u64(k)), nm
+        for n2 in ((1 << 20) + 77, 3000001, (1 << 25) + 4321, (1 << 27) + 99):   # all three tile tiers of the finish
+            k = oracle.keys_u64(n2, seed=n2 & 0xff)
+            assert np.array_equal(gpu_sort_u64(dev, p, k), oracle.sort_u64(k)), n2
+        dev.setParam("sort.binfinish", 1)   # the default: binning from 24 Mi keys, the LSD finish below
+        k = oracle.keys_u64(n, seed=6)
+        got, prof = _profiled(dev, lambda: gpu_sort_u64(dev, p, k))
+        assert set(prof) == LARGE_U64_LSD, prof
+        assert np.array_equal(got, oracle.sort_u64(k))
+        k = oracle.keys_u64((1 << 25) + 3, seed=7)
+        got, prof = _profiled(dev, lambda: gpu_sort_u64(dev, p, k))
+        assert set(prof) == LARGE_U64_BIN, prof
+        assert np.array_equal(got, oracle.sort_u64(k))
+        dev.setParam("sort.msd2", 2)        # forced, forms as the automatic choice takes them: 32 Mi + 3 keys -> stable passes
+        got, prof = _profiled(dev, lambda: gpu_sort_u64(dev, p, k))
+        assert set(prof) == LARGE_U64_BIN, prof
+        k = oracle.keys_u64((1 << 24) + 3, seed=8)   # ... 16 Mi + 3 keys -> cursor passes, LSD finish
+        got, prof = _profiled(dev, lambda: gpu_sort_u64(dev, p, k))
+        assert set(prof) == {"msd2_sample", "msd2_pass1_u64", "msd2_pass2_u64", "msd2_offsets", "segment_sort_wave_e64"}, prof
+        assert np.array_equal(got, oracle.sort_u64(k))
+        k = oracle.keys_u64((1 << 25) + 3, seed=7)
+        dev.setParam("sort.msd2", 4)        # cursor passes
+        got, prof = _profiled(dev, lambda: gpu_sort_u64(dev, p, k))
+        assert {"msd2_pass1_u64", "msd2_pass2_u64", "segment_sort_bin_u64"} <= set(prof), prof
+        assert np.array_equal(got, oracle.sort_u64(k))
+        DeviceUtils.waitForCompletion(dev)
+    finally:
+        dev.setParam("sort.msd2", 1)
+        dev.setParam("sort.binfinish", 1)
+        p.close()
+
+
+def test_small_partition_keeps_off_the_paths_with_a_grid_barrier(dev):
+    """A device (or partition) that cannot keep 256 workgroups resident must not take the paths whose safety nets hold a grid-wide
+    barrier over 256 workgroups, nor the one-workgroup-per-bucket finish ("debug.resident_wgs" stands in for such a device): the
+    per-digit passes run instead and the result is right."""
+    set_algo(dev, (-1, 8, -1))
+    p = Pprims()
+    real = dev.getParam("debug.resident_wgs")
+    assert real >= 256, real
+    try:
+        dev.setParam("debug.resident_wgs", 120)
+        for n in (300007, (1 << 22) + 5):
+            keys = oracle.keys_u32(n, seed=3)
+            got, prof = _profiled(dev, lambda: gpu_sort_u32(dev, p, keys))
+            assert not any(k.startswith(("mid_", "msd2", "segment_sort")) for k in prof), prof
+            assert np.array_equal(got, oracle.sort_u32(keys)), n
+    finally:
+        dev.setParam("debug.resident_wgs", 0)
+        assert dev.getParam("debug.resident_wgs") == real
+        p.close()
