@@ -17,11 +17,14 @@ Every step sorts its OWN pre-generated random buffer (K + W buffers of 256 MiB a
 device before the timed region), so no step sees pre-sorted data and no restore copy is timed.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline     : dominant kernel (the pass that sorts a tile by one digit and scatters it: the MSD bucket pass of the
-                 large keys-only sort, the one-sweep pass otherwise), ALGORITHMIC bytes per launch =
-                 2*n*E (read n*E + write n*E) / its average launch duration,
-                 measured here with hipEvents on the library's own stream in a second, profiled loop
-                 over the same inputs (toggleProfiling brackets every launch with an event pair).
+  roofline     : dominant kernel = the launch kind of a sort that takes the most time (pass 1 of the large sort at N = 1),
+                 ALGORITHMIC bytes per launch (what that sweep must read and write; SURVEY.md section 8d's n*E read +
+                 n*E write, less where a slab holds 16-bit keys) / its average launch duration, measured here with
+                 hipEvents on the library's own stream in a second, profiled loop over the same inputs
+                 (toggleProfiling brackets every launch with an event pair).  roofline.by_kernel lists every sweep of
+                 the sort the same way (pass 1 / pass 2 / finish); roofline.traffic = HBM bytes per launch of the
+                 dominant kernel from FETCH_SIZE / WRITE_SIZE, collected by two child runs of this file under
+                 `rocprofv3 --kernel-trace --pmc ...` (separate passes, kernel trace only) when rocprofv3 is there.
   cpu_baseline : the reference's single-threaded CPU sort (oracle/_ref, else the oracle port) timed on
                  this host on the same 64Mi-key workload (N = 1, rank 0 only).
 """
@@ -77,6 +80,75 @@ def cpu_baseline(n):
                       % (len(times), n, best, cpu_model, os.cpu_count() or 0)}, fn
 
 
+# rocprofv3 kernel names of the launch kinds bench.py prices (csrc/adlhip.hip launch names -> substrings of the kernel's name)
+PMC_KERNEL = {
+    "msd2_pass1_u32": "msd_bucket_scatter_kernel<unsigned int, 512, 32, 1>",
+    "msd2_pass2_u32": "msd_bucket_scatter_kernel<unsigned int, 512, 32, 2>",
+    "segment_sort_wave_u32": "wave_segment_sort_kernel<unsigned int",
+    "onesweep_u32_8b": "onesweep_chain_kernel",
+}
+
+
+def pmc_child(n, steps):
+    """What a `rocprofv3 --pmc` pass of this file runs: the sorts and nothing else."""
+    from oclradixsort_amd import Buffer, DeviceUtils, Pprims
+    d = DeviceUtils.allocate()
+    p = Pprims()
+    bufs = [Buffer(d, n, np.uint32) for _ in range(steps + 1)]
+    for i, b in enumerate(bufs):
+        b.generate(n, seed=123 + i)
+    for b in bufs:
+        p.radixSort(d, b, n)
+    DeviceUtils.waitForCompletion(d)
+    for b in bufs:
+        b.release()
+    p.close()
+    DeviceUtils.deallocate(d)
+
+
+def measure_traffic(n, launch_names):
+    """HBM bytes per launch of the named launch kinds: FETCH_SIZE and WRITE_SIZE in their own rocprofv3 passes (kernel trace only),
+    corrected as MI355X_MICROARCH.md's HBM section prescribes for gfx950 (both in KiB; FETCH_SIZE counts half of the bytes of a
+    streaming read -> x2).  Returns {launch name: {...}} or raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    res = {k: {} for k in launch_names}
+    tmp = tempfile.mkdtemp(prefix="adlhip_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--n", str(n), "--steps", "3"]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            acc = {k: [0.0, 0] for k in launch_names}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") != ctr:
+                            continue
+                        for k in launch_names:
+                            if PMC_KERNEL[k] in row.get("Kernel_Name", ""):
+                                acc[k][0] += float(row["Counter_Value"])
+                                acc[k][1] += 1
+            for k in launch_names:
+                if acc[k][1] == 0:
+                    raise RuntimeError("no %s rows for %s" % (ctr, k))
+                res[k][ctr + "_kb"] = acc[k][0] / acc[k][1]
+                res[k]["launches_averaged"] = acc[k][1]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for k in launch_names:
+        res[k]["traffic_bytes_per_launch"] = int(res[k]["FETCH_SIZE_kb"] * 1024 * 2.0 + res[k]["WRITE_SIZE_kb"] * 1024)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,7 +162,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config #3 / #5 extras beside the metric")
+    ap.add_argument("--no-pmc", action="store_true", help="do not start the two rocprofv3 --pmc child runs for roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        pmc_child(args.n, args.steps)
+        return
 
     import torch
     import torch.distributed as dist
@@ -247,15 +324,15 @@ def main():
                     s3.stop()
                     ms = s3.getMs() / reps
                     entry = {"value": nn / ms / 1e6, "unit": unit, "ms_per_sort": ms, "elements": nn, "sorts_timed": reps}
-                    if not args.no_verify:
+                    if not args.no_verify:   # outside the timing: one result against the oracle, bit for bit
+                        import oracle
                         got = bb[1].toHost()
-                        keys = (got & np.uint64(0xffffffff)) if gen == 1 else got
-                        entry["sorted"] = bool(np.all(keys[1:] >= keys[:-1]))
-                        if gen == 1:   # stability: values are the input indices, so they rise within a run of equal keys
-                            same = keys[1:] == keys[:-1]
-                            vals = got >> np.uint64(32)
-                            entry["stable"] = bool(np.all(vals[1:][same] > vals[:-1][same]))
-                        del got, keys
+                        want = (oracle.sort_kv32(oracle.pairs_kv32(nn, seed=901)) if gen == 1
+                                else oracle.sort_u64(oracle.keys_u64(nn, seed=901)))
+                        entry["verified_vs_oracle"] = bool(np.array_equal(got, want))
+                        del got, want
+                        if not entry["verified_vs_oracle"]:
+                            raise SystemExit("bench: %s differs from the oracle" % label)
                     for b in bb:
                         b.release()
                     others[label] = entry
@@ -266,11 +343,10 @@ def main():
         info_name = d.getDeviceName()
         DeviceUtils.deallocate(d)
 
-        # the kernels that move the whole array once (read n*E + write n*E per launch), grouped by KERNEL as rocprofv3 sees
-        # them: the two MSD bucket passes of the large keys-only sort are two launches of one kernel
-        # algorithmic bytes of one launch (what the step must read and write): a per-digit pass reads and
+        # Every sweep of the sort priced on its own (pass 1 / pass 2 / finish of the large sort; the per-digit passes otherwise)
+        # by the ALGORITHMIC bytes of one launch (what the step must read and write): a pass reads and
         # writes the array; in the large sort the second slab holds the keys' low 16 bits only, so its second pass writes 2 bytes
-        # per key and its finish reads 2
+        # per key and its finish reads 2.
         large = "msd2_pass1_u32" in prof
         def alg_bytes(k):
             if k == "msd2_pass2_u32":
@@ -278,39 +354,56 @@ def main():
             if k.startswith("segment_sort") and large:
                 return n * (2 + ELEM_BYTES)
             return 2 * n * ELEM_BYTES
-        groups = {}   # name -> (launches, ms, algorithmic bytes over all launches)
+        groups = {}   # launch name -> (launches, ms, algorithmic bytes over all launches)
         for k, v in prof.items():
-            if k.startswith(("onesweep_", "scatter_", "segment_sort")):
+            if k.startswith(("onesweep_", "scatter_", "segment_sort", "msd2_pass", "msd2s_pass")):
                 groups[k] = (v[0], v[1], v[0] * alg_bytes(k))
-            elif k.startswith("msd2_pass"):
-                g = groups.get("msd2_pass_u32", (0, 0.0, 0))
-                groups["msd2_pass_u32"] = (g[0] + v[0], g[1] + v[1], g[2] + v[0] * alg_bytes(k))
         dom_name, (dom_launches, dom_ms, dom_bytes) = max(groups.items(), key=lambda kv: kv[1][1])
         dom_avg_s = dom_ms / dom_launches * 1e-3
         achieved = dom_bytes / dom_launches / dom_avg_s / 1e9
-        # HBM traffic per launch from PMC counters: collected in separate rocprofv3 --pmc passes of this same
-        # command (tools/gpu_session.sh) and stored under profiles/; used only if it is for this kernel and size
-        traffic, traffic_src = None, None
-        try:
-            import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
-                t = json.load(open(f))
-                if (t.get("profile_name") == dom_name and t.get("keys_per_launch") == n
-                        and abs(t.get("algorithmic_bytes_per_launch", 0) - dom_bytes / dom_launches) < 1e-3 * dom_bytes / dom_launches):
-                    traffic, traffic_src = t["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
-                    break
-        except Exception:
-            pass
+        # HBM traffic per launch from the PMC counters, measured now: two child runs of this file under rocprofv3 (one counter
+        # each, kernel trace only -- MI355X_MICROARCH.md's recipe); the committed figures of the round's profiling session
+        # (profiles/*pmc_traffic.json) stand in only when rocprofv3 cannot be run here
+        traffic, traffic_src, traffic_all = None, None, {}
+        if not args.no_pmc and n == N_KEYS:
+            try:
+                names = [k for k in groups if k in PMC_KERNEL]
+                traffic_all = measure_traffic(n, names)
+                traffic = traffic_all[dom_name]["traffic_bytes_per_launch"]
+                traffic_src = "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, two child runs"
+            except Exception as e:
+                traffic_all = {"error": repr(e)[:200]}
+        if traffic is None:
+            try:
+                import glob
+                for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+                    t = json.load(open(f))
+                    if (t.get("profile_name") == dom_name and t.get("keys_per_launch") == n
+                            and abs(t.get("algorithmic_bytes_per_launch", 0) - dom_bytes / dom_launches) < 1e-3 * dom_bytes / dom_launches):
+                        traffic, traffic_src = t["traffic_bytes_per_launch"], os.path.relpath(f, ROOT) + " (committed; not measured in this run)"
+                        break
+            except Exception:
+                pass
+        by_kernel = []
+        for k, (ln, ms, by) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+            ach = by / ln / (ms / ln * 1e-3) / 1e9
+            row = {"kernel": k, "launches": ln, "avg_launch_ms": ms / ln, "algorithmic_bytes_per_launch": by / ln,
+                   "achieved": ach, "frac": ach / HBM_PEAK_GBS}
+            if isinstance(traffic_all.get(k), dict) and "traffic_bytes_per_launch" in traffic_all[k]:
+                row["traffic"] = traffic_all[k]["traffic_bytes_per_launch"]
+                row["fetch_kb"] = traffic_all[k]["FETCH_SIZE_kb"]
+                row["write_kb"] = traffic_all[k]["WRITE_SIZE_kb"]
+            by_kernel.append(row)
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": dom_name, "launches": dom_launches, "avg_launch_ms": dom_ms / dom_launches,
+            "kernel": dom_name, "rocprof_kernel": PMC_KERNEL.get(dom_name), "launches": dom_launches, "avg_launch_ms": dom_ms / dom_launches,
             "algorithmic_bytes_per_launch": dom_bytes / dom_launches,
             "timing": "hipEvent pair around every launch on the library's stream, second loop over the same K inputs",
+            "by_kernel": by_kernel,
         }
-        if dom_name == "msd2_pass_u32":
-            out["roofline"]["note"] = ("two launches of one kernel per sort: pass 1 reads and writes 4 bytes per key, pass 2 reads 4 and "
-                                       "writes 2 (the second slab holds the keys' low 16 bits); bytes and time are averaged over both")
+        if "error" in traffic_all:
+            out["roofline"]["traffic_error"] = traffic_all["error"]
         out["kernels"] = {k: {"launches": v[0], "avg_ms": v[1] / v[0]} for k, v in prof.items()}
         out["probe"] = probe
         out["device"] = info_name
@@ -325,7 +418,7 @@ def main():
                              "frac_of_peak": n * moved / (ev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS}
         parallelism = "1 GPU"
         workload = "Key-only RadixSort32, %d uniform-random u32 keys (splitmix64 hi32, seed 123+step), 1xMI355X, in place" % n
-        auto = "auto (two MSD bucket passes + LDS finish at this size)" if "msd2_pass1_u32" in prof else "auto (one-sweep at this size)"
+        auto = "auto (two MSD bucket passes + LDS finish at this size)" if large else "auto (one-sweep at this size)"
         algo_name = {0: "onesweep", 1: "three-kernel", -1: auto}.get(algo, str(algo))
         cfg_extra = {"sort_algo": algo_name, "digit_bits": digit_bits}
     else:

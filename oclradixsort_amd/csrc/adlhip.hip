@@ -890,7 +890,7 @@ int mid_sort_keys(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, s
     E* slab = reinterpret_cast<E*>(wb + L.off_slab);
     uint32_t* state = d->d_mid_hist + 16 * 1024;
     using CA = adlhip::TileCfg<E, 8, 256, 16>;
-    auto ka = adlhip::msd_bucket_scatter_kernel<E, 256, 16>;
+    auto ka = adlhip::msd_bucket_scatter_kernel<E, 256, 16, 0>;
     if (ensure_lds(ka, CA::LDS_BYTES)) return ADLHIP_FAILURE;
     const uint32_t tiles = (uint32_t)((n + kMidTile - 1) / kMidTile);
     adlhip::BucketPass<E> pa;
@@ -1037,8 +1037,9 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     E* slab_a = reinterpret_cast<E*>(wb + L.off_slab_a);
     E* slab_b = reinterpret_cast<E*>(wb + L.off_slab_b);
     using CT = adlhip::TileCfg<E, 8, 512, K>;
-    auto kern = adlhip::msd_bucket_scatter_kernel<E, 512, K>;
-    if (ensure_lds(kern, CT::LDS_BYTES)) return ADLHIP_FAILURE;
+    auto kern = adlhip::msd_bucket_scatter_kernel<E, 512, K, 1>;
+    auto kern2 = adlhip::msd_bucket_scatter_kernel<E, 512, K, 2>;
+    if (ensure_lds(kern, CT::LDS_BYTES) || ensure_lds(kern2, CT::LDS_BYTES)) return ADLHIP_FAILURE;
     // where the two digits sit is chosen on the device from a sample of the keys (hybrid_kernels.hpp msd2_sample_kernel)
     int rc = launch(d, "msd2_sample", [&] {
         hipLaunchKernelGGL(adlhip::msd2_sample_kernel<E>, dim3(adlhip::kSampleWGs), dim3(64), 0, d->stream, (const E*)data, (uint32_t)n,
@@ -1061,7 +1062,7 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     pb.sample = sample; pb.which_digit = 2;
     pb.dst16 = sizeof(E) == 4 ? 1 : 0;   // u32 keys: the second slab holds the low 16 bits only
     rc = launch(d, k32 ? "msd2_pass2_u32" : "msd2_pass2_u64", [&] {
-        hipLaunchKernelGGL(kern, dim3(256 * L.tiles_per_bucket), dim3(512), CT::LDS_BYTES, d->stream, pb);
+        hipLaunchKernelGGL(kern2, dim3(256 * L.tiles_per_bucket), dim3(512), CT::LDS_BYTES, d->stream, pb);
     });
     if (rc) return rc;
     // segment sizes and offsets -- and, when a run did not fit its slab, the safety net: the same 256 resident workgroups sort

@@ -905,7 +905,10 @@ __global__ __launch_bounds__(64) void msd2_sample_kernel(const E* __restrict__ s
 // look-back: load (wave-striped) -> rank (returning DS atomics) | barrier | every wave folds the counts and writes its own
 // 16-bit positions; wave 0 reserves the tile's 256 runs with returning atomics on the bucket cursors while all waves
 // scatter into LDS | barrier | write-out, consecutive lanes to consecutive addresses of a run.
-template <typename E, int NT, int K>
+// PASS: 0 = the mid-size sort's single pass, 1 / 2 = first / second pass of the large sort -- the same code (everything it
+// switches on is in BucketPass); the parameter only gives the launches of a sort kernel names of their own, so that rocprofv3's
+// per-kernel statistics and counters tell pass 1 from pass 2.
+template <typename E, int NT, int K, int PASS>
 __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
 {
     using C = TileCfg<E, 8, NT, K>;
