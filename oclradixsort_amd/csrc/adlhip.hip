@@ -898,6 +898,7 @@ int mid_sort_keys(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, s
     pa.src_counts = nullptr; pa.n = (uint32_t)n; pa.src_stride = 0; pa.tiles_per_bucket = 1; pa.dst_stride = L.stride;
     pa.dst_total = 256u * L.stride; pa.start_bit = 24; pa.zero_me = state + 8194;
     pa.sample = nullptr; pa.which_digit = 0; pa.dst16 = 0;
+    pa.place = nullptr; pa.status_a = nullptr; pa.pieces = 0; pa.rows_per_chain_a = 0; pa.slice = 0;
     int rc = launch(d, "mid_bucket_scatter_u32", [&] {
         hipLaunchKernelGGL(ka, dim3(tiles), dim3(256), CA::LDS_BYTES, d->stream, pa);
     });
@@ -1051,10 +1052,11 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     pa.src_counts = nullptr; pa.n = (uint32_t)n;
     pa.src_stride = 0; pa.tiles_per_bucket = 1; pa.dst_stride = L.stride_a; pa.dst_total = 256u * L.stride_a; pa.start_bit = KEY_BITS - 8;
     pa.zero_me = nullptr; pa.sample = sample; pa.which_digit = 1; pa.dst16 = 0;
+    pa.place = nullptr; pa.status_a = nullptr; pa.pieces = 0; pa.rows_per_chain_a = 0; pa.slice = 0;
     const uint32_t tiles_a = (uint32_t)((n + CT::TILE - 1) / CT::TILE);
     rc = launch(d, k32 ? "msd2_pass1_u32" : "msd2_pass1_u64", [&] { hipLaunchKernelGGL(kern, dim3(tiles_a), dim3(512), CT::LDS_BYTES, d->stream, pa); });
     if (rc) return rc;
-    adlhip::BucketPass<E> pb;   // pass 2: every bucket, second digit -> 65536 segment slabs
+    adlhip::BucketPass<E> pb = pa;   // pass 2: every bucket, second digit -> 65536 segment slabs
     pb.src = slab_a; pb.dst = slab_b; pb.cursors = cur_b; pb.cursor_shift = 0; pb.src_count_shift = 5; pb.flag = flag;
     pb.src_counts = cur_a; pb.n = (uint32_t)n;
     pb.src_stride = L.stride_a; pb.tiles_per_bucket = L.tiles_per_bucket; pb.dst_stride = L.stride_b;
@@ -1151,11 +1153,12 @@ Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8)
 }
 
 // Which sorts take the large sort, and in which form.  keys: the element is the key (u32 / u64 keys), else {key, value} pairs.
-//   whole u32 keys                      -> cursor passes + 16-bit second slab (msd2_sort)      ["sort.msd2" = 3: stable passes]
-//   whole u64 keys, 32 Mi keys and more -> stable passes + binning finish (msd2s_sort)          ["sort.msd2" = 4: cursor passes,
-//   whole u64 keys below                -> cursor passes (msd2_sort)                             3: stable passes, at every size]
-//   pairs; partial sortBits (>= 16)     -> stable passes + LSD finish (msd2s_sort)
-enum LargeForm { kLargeNone = 0, kLargeCursor, kLargeStable };
+//   whole u32 keys from 96 Mi keys               -> hybrid: stable first pass + cursor-placed second pass (msd2s_sort, hybrid)
+//   whole u64 keys from 48 Mi keys               -> stable passes (msd2s_sort) + binning finish
+//   whole keys below                            -> cursor passes (msd2_sort: smaller fixed cost)
+//   pairs; partial sortBits (>= 16)             -> stable passes (msd2s_sort)
+// "sort.msd2" = 3 / 4 / 5 force the stable / cursor / hybrid form where it applies (tests, A/B measurements).
+enum LargeForm { kLargeNone = 0, kLargeCursor, kLargeStable, kLargeHybrid };
 LargeForm large_sort_form(const adlhip_device* d, size_t elem_bytes, bool keys, size_t n, int sort_bits, int max_bits)
 {
     if (!(d->sort_algo < 0 && d->msd2_path && d->rank_mode == 1 && d->digit_bits == 8 && d->tile_variant < 0)) return kLargeNone;
@@ -1165,12 +1168,15 @@ LargeForm large_sort_form(const adlhip_device* d, size_t elem_bytes, bool keys, 
     const bool whole = sort_bits == max_bits;
     if (!keys) return n > (forced ? kMsd2Min : kMsd2sAutoMin) && n <= kMsd2sMax ? kLargeStable : kLargeNone;
     if (n <= (forced ? kMsd2Min : kMsd2AutoMin)) return kLargeNone;
-    // whole u64 keys: the stable passes win from ~32 Mi keys (256 Mi: 2.93 vs 3.13 ms, 64 Mi: 0.850 vs 0.872), the cursor passes with
-    // their smaller fixed cost below (16 Mi: 0.288 vs 0.318 ms; profiles/r3_u64_stable_vs_cursor.txt)
-    const bool cursor = whole && (elem_bytes == 4 ? d->msd2_path != 3
-                                                  : (d->msd2_path == 4 || (d->msd2_path < 3 && n < (size_t(32) << 20))));
-    if (cursor) return n <= (elem_bytes == 4 ? kMsd2MaxU32 : kMsd2MaxU64) ? kLargeCursor : kLargeNone;
-    return n <= kMsd2sMax ? kLargeStable : kLargeNone;
+    const size_t cursor_max = elem_bytes == 4 ? kMsd2MaxU32 : kMsd2MaxU64;
+    if (!whole || d->msd2_path == 3) return n <= kMsd2sMax ? kLargeStable : kLargeNone;
+    if (d->msd2_path == 4) return n <= cursor_max ? kLargeCursor : kLargeNone;
+    if (d->msd2_path == 5) return n <= kMsd2sMax ? kLargeHybrid : kLargeNone;
+    // profiles/r3_forms_by_size.txt -- u32 keys: cursor | hybrid 64 Mi 0.424 | 0.423 ms, 128 Mi 0.782 | 0.751, 256 Mi 1.700 | 1.620
+    // (16 Mi: 0.140 | 0.159); u64 keys: cursor | stable 16 Mi 0.294 | 0.312, 64 Mi 0.846 | 0.803, 256 Mi 3.18 | 2.99 (hybrid 2.96)
+    if (elem_bytes == 4 && n >= (size_t(96) << 20) && n <= kMsd2sMax) return kLargeHybrid;
+    if (elem_bytes == 8 && n >= (size_t(48) << 20) && n <= kMsd2sMax) return kLargeStable;
+    return n <= cursor_max ? kLargeCursor : kLargeNone;
 }
 
 // The finish of either large sort: the binning finish (whole u64 keys from ~24 Mi up: one counting pass + compares, then the
@@ -1215,9 +1221,14 @@ bool use_bin_finish(const adlhip_device* d, size_t elem_bytes, bool key64, size_
 // 16 bits, as in the cursor form).  sort_bits < key bits (Pprims.cpp:357, a multiple of 4, at least 16 here): only the low sort_bits
 // bits of a key count -- the digits are placed inside them, everything is stable, so keys that agree there keep their input order
 // as the reference's LSD passes would leave them.
+// hybrid (whole keys only -- equal keys are indistinguishable, so the second pass need not be stable): pass A as above, then the
+// CURSOR-placed second pass of the keys-only form over buckets made of pass A's sub-slabs (msd_bucket_scatter_kernel, PASS = 3).
+// Measured per pass at 64 Mi u32 keys: first pass 0.138 ms by look-back vs 0.147-0.159 with cursors (the abutting runs of a
+// chain's consecutive tiles meet in one XCD's L2: 1.05 x instead of 1.21 x bytes written), second pass 0.124 with cursors vs
+// 0.172 by look-back (profiles/r3_first_ab_cursor_vs_lookback_u32.txt).
 template <typename E, bool KEY64>
 int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort_bits, uint32_t* soa_keys = nullptr,
-               uint32_t* soa_vals = nullptr)
+               uint32_t* soa_vals = nullptr, bool hybrid = false)
 {
     constexpr int K = sizeof(E) == 8 ? 16 : 32;
     constexpr bool k32 = sizeof(E) == 4;
@@ -1248,8 +1259,8 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
     static_assert(CT::TILE == (int)msd2s_tile(sizeof(E)), "layout and kernel agree on the tile");
     auto kern = adlhip::msd_lookback_scatter_kernel<E, 512, K, KEY64>;
     if (ensure_lds(kern, CT::LDS_BYTES)) return ADLHIP_FAILURE;
-    // status rows of both passes: zero (one memset; the rows are contiguous)
-    HIPCHK(hipMemsetAsync(status_a, 0, (L.off_status_b - L.off_status_a) + L.status_bytes_b, d->stream));
+    // status rows of both passes: zero (one memset; the rows are contiguous).  Hybrid: pass A's only.
+    HIPCHK(hipMemsetAsync(status_a, 0, hybrid ? L.status_bytes_a : (L.off_status_b - L.off_status_a) + L.status_bytes_b, d->stream));
     int rc = launch(d, "msd2s_prep", [&] {
         if (soa_keys)
             hipLaunchKernelGGL((adlhip::msd2s_prep_kernel<uint32_t, false>), dim3(1), dim3(1024), 0, d->stream, (const uint32_t*)soa_keys,
@@ -1269,25 +1280,46 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
         hipLaunchKernelGGL(kern, dim3(L.pieces * L.rows_a), dim3(512), CT::LDS_BYTES, d->stream, pa);
     });
     if (rc) return rc;
+    const bool slab16 = k32 && whole;   // whole u32 keys: a segment's keys share everything above their low 16 bits
+    uint32_t* cur_b = nullptr;
+    if constexpr (sizeof(E) == 4 || KEY64) {
+        if (hybrid) {
+            if (!whole || soa_keys) return fail("internal: the hybrid form sorts whole keys only");
+            cur_b = d->d_msd2 + 8192;   // 65536 cursors [bucket][digit], zero between sorts (the offsets kernel clears them)
+            auto kern2 = adlhip::msd_bucket_scatter_kernel<E, 512, K, 3>;
+            if (ensure_lds(kern2, CT::LDS_BYTES)) return ADLHIP_FAILURE;
+            adlhip::BucketPass<E> pc;
+            pc.src = slab_a; pc.dst = slab_b; pc.cursors = cur_b; pc.cursor_shift = 0; pc.src_count_shift = 0; pc.flag = flag;
+            pc.src_counts = nullptr; pc.n = (uint32_t)n; pc.src_stride = L.stride_a; pc.tiles_per_bucket = L.rows_b;
+            pc.dst_stride = L.stride_b; pc.dst_total = 65536u * L.stride_b; pc.start_bit = 0; pc.zero_me = nullptr; pc.sample = nullptr;
+            pc.which_digit = 2; pc.dst16 = slab16 ? 1 : 0;
+            pc.place = place; pc.status_a = status_a; pc.pieces = L.pieces; pc.rows_per_chain_a = L.rows_a; pc.slice = L.slice;
+            rc = launch(d, k32 ? "msd2h_pass2_u32" : "msd2h_pass2_u64", [&] {
+                hipLaunchKernelGGL(kern2, dim3(256 * L.rows_b), dim3(512), CT::LDS_BYTES, d->stream, pc);
+            });
+            if (rc) return rc;
+        }
+    }
     adlhip::LookbackPass<E> pb = pa;
     pb.src = slab_a; pb.dst = slab_b; pb.status = status_b; pb.status_bytes = (uint32_t)L.status_bytes_b;
     pb.tickets = tickets + 32 * adlhip::kTicketStride; pb.which_digit = 2; pb.chains = 256; pb.rows_per_chain = L.rows_b;
     pb.src_stride = L.stride_a; pb.status_a = status_a; pb.rows_per_chain_a = L.rows_a; pb.dst_stride = L.stride_b;
     pb.dst_total = 65536u * L.stride_b;
     pb.soa_keys = nullptr; pb.soa_vals = nullptr;
-    const bool slab16 = k32 && whole;   // whole u32 keys: a segment's keys share everything above their low 16 bits
     pb.dst16 = slab16 ? 1 : 0;
-    rc = launch(d, k32 ? "msd2s_pass2_u32" : KEY64 ? "msd2s_pass2_u64" : soa_keys ? "msd2s_pass2_soa" : "msd2s_pass2_kv32", [&] {
-        hipLaunchKernelGGL(kern, dim3(256 * L.rows_b), dim3(512), CT::LDS_BYTES, d->stream, pb);
-    });
-    if (rc) return rc;
+    if (!cur_b) {
+        rc = launch(d, k32 ? "msd2s_pass2_u32" : KEY64 ? "msd2s_pass2_u64" : soa_keys ? "msd2s_pass2_soa" : "msd2s_pass2_kv32", [&] {
+            hipLaunchKernelGGL(kern, dim3(256 * L.rows_b), dim3(512), CT::LDS_BYTES, d->stream, pb);
+        });
+        if (rc) return rc;
+    }
     uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
     using CC = adlhip::TileCfg<E, 8, 256, 16>;   // the safety net's tile (it runs in the offsets kernel when a run did not fit)
     rc = launch(d, "msd2s_offsets", [&] {
         hipLaunchKernelGGL((adlhip::msd2s_offsets_kernel<E, CT::TILE>), dim3(256), dim3(256), CC::LDS_BYTES, d->stream,
                            (const uint32_t*)status_a, L.rows_a, L.slice, L.pieces, (const uint32_t*)status_b, L.rows_b, L.stride_a, flag,
                            done, bar, seg_cnt, seg_off, mode, d->h_fault + 11, (uint32_t)n, (const adlhip::StablePlace*)place,
-                           soa_keys ? slab_a : data, soa_keys ? slab_b : tmp, ctable, d->d_fault, soa_keys, soa_vals);
+                           soa_keys ? slab_a : data, soa_keys ? slab_b : tmp, ctable, d->d_fault, soa_keys, soa_vals, cur_b);
     });
     if (rc) return rc;
     const int low_max = sort_bits - 16;
@@ -1388,10 +1420,11 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
         const Msd2Choice c = msd2_decide(d);
         if (c == kMsd2Use) {
             if (form == kLargeCursor) return msd2_sort<E>(d, data, tmp, work, n);
+            const bool hybrid = form == kLargeHybrid;
             if constexpr (sizeof(E) == 4) {
-                return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits);
+                return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits, nullptr, nullptr, hybrid);
             } else {
-                if (keys) return msd2s_sort<E, true>(d, data, tmp, work, n, sort_bits);
+                if (keys) return msd2s_sort<E, true>(d, data, tmp, work, n, sort_bits, nullptr, nullptr, hybrid);
                 return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits);
             }
         }
@@ -2030,9 +2063,9 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
         if (value < 0 || value > 3) return fail("sort.mid must be 0 (off), 1 (on), 2 (keys: always the two-launch form) or 3 (always the three-launch form)");
         d->mid_path = value;
     } else if (!strcmp(name, "sort.msd2")) {
-        if (value < 0 || value > 4)
-            return fail("sort.msd2 must be 0 (off), 1 (on), 2 (always, whatever the hints say), 3 (always; whole u32 keys through the stable "
-                        "passes too) or 4 (always; whole u64 keys through the cursor passes)");
+        if (value < 0 || value > 5)
+            return fail("sort.msd2 must be 0 (off), 1 (on), 2 (always, whatever the hints say; forms by size), 3 (always the stable passes), "
+                        "4 (always the cursor passes for whole keys) or 5 (always the hybrid form for whole keys)");
         d->msd2_path = value;
     } else if (!strcmp(name, "sort.binfinish")) {
         if (value < 0 || value > 2) return fail("sort.binfinish must be 0 (LSD finish), 1 (binning finish for whole u64 keys from 24 Mi keys up) or 2 (always, u32 keys too)");

@@ -770,6 +770,23 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void bin_segment_sort_kern
 // One kernel serves the single MSD pass of the mid-size sort (linear input) and both MSD passes of the large keys-only sort
 // (the second pass reads the buckets of the first: workgroup -> (source bucket, tile inside it), tiles beyond the bucket's
 // count return at once; its cursors are indexed (source bucket, digit)).
+struct StablePlace {   // written by msd2s_prep_kernel
+    uint32_t top;      // one past the highest key bit (below sort_bits) in which two sampled keys differ (>= 16)
+    uint32_t low_bits; // top - 16: what the finish sorts
+    uint32_t sort_bits;
+    uint32_t pad;
+    unsigned long long prefix;   // (key & mask(sort_bits)) >> top of every key (top < key bits)
+    unsigned long long kmask;    // mask(sort_bits)
+};
+
+// The key of an element: the whole element (u32 keys; u64 keys: KEY64), or the low dword of a {key, value} pair.
+template <bool KEY64, typename E>
+__device__ __forceinline__ unsigned long long key_of(E e)
+{
+    if constexpr (KEY64) return (unsigned long long)e;
+    else return (unsigned long long)(uint32_t)e;
+}
+
 template <typename E>
 struct BucketPass {
     const E* src;
@@ -793,6 +810,12 @@ struct BucketPass {
     int dst16;                    // the destination slabs hold uint16_t: only the key's low 16 bits are written (the second pass of
                                   // u32 keys: the bits above are the segment's number -- 128 MiB less to write and to read back
                                   // at 64 Mi keys)
+    // PASS == 3, the second pass of the hybrid form: the first pass was the STABLE one (msd_lookback_scatter_kernel, pass A), so
+    // a source bucket is made of `pieces` sub-slabs (one per chain of pass A) whose sizes are the last status rows of pass A's
+    // chains, and the digits' place comes from msd2s_prep_kernel
+    const StablePlace* place;
+    const uint32_t* status_a;
+    uint32_t pieces, rows_per_chain_a, slice;
 };
 
 // Digit placement of the large keys-only sort, chosen on the device from a sample of the keys: keys that do not use their top
@@ -921,7 +944,70 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
     uint32_t* __restrict__ s_goff = reinterpret_cast<uint32_t*>(smem + C::OFF_GOFF);   // [BINS]
     if (a.zero_me && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.zero_me, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t base, valid, cursor_base = 0u;
-    if (a.src_counts == nullptr) {
+    uint32_t lin = 0u;   // PASS == 3: index of the tile's first element if the tile lies inside one sub-slab, else ~0
+    if constexpr (PASS == 3) {
+        // workgroup -> (bucket, tile of the bucket); the bucket = its sub-slabs one after the other (see LookbackPass, pass B)
+        uint32_t* __restrict__ s_misc = reinterpret_cast<uint32_t*>(smem + C::OFF_MISC);
+        const uint32_t b = blockIdx.x / a.tiles_per_bucket, t = blockIdx.x % a.tiles_per_bucket;
+        if (threadIdx.x < 64u) {
+            const int l = (int)threadIdx.x;
+            uint32_t cnt = 0u;
+            if ((uint32_t)l < a.pieces) {
+                const uint32_t c0 = (uint32_t)l * a.slice;
+                if (c0 < a.n) {
+                    const uint32_t len = (c0 + a.slice < a.n ? c0 + a.slice : a.n) - c0;
+                    const uint32_t rows = (len + (uint32_t)C::TILE - 1u) / (uint32_t)C::TILE;
+                    cnt = a.status_a[((size_t)l * a.rows_per_chain_a + rows - 1u) * BINS + b] & kValMask;
+                    if (cnt > a.src_stride) cnt = a.src_stride;   // overflowed in pass A: the flag is set, only stay in bounds
+                }
+            }
+            const uint32_t incl = wave_incl_scan_u32(cnt);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (l < 32) {
+                const bool real = (uint32_t)l < a.pieces;
+                s_goff[l] = real ? incl : 0xffffffffu;
+                s_goff[32 + l] = real ? (b * a.pieces + (uint32_t)l) * a.src_stride - (incl - cnt) : 0u;
+            }
+            const uint32_t pos = t * (uint32_t)C::TILE;   // position in the bucket
+            uint32_t v = 0u;
+            if (pos < total) v = total - pos < (uint32_t)C::TILE ? total - pos : (uint32_t)C::TILE;
+            // the sub-slab the tile starts in, and the next one that holds anything: a tile that lies inside those two (with
+            // sub-slabs of about a tile's size: nearly every tile) is loaded as two stretches -- one compare per element
+            const unsigned long long after = __ballot((uint32_t)l < a.pieces && incl > pos && cnt != 0u);
+            uint32_t ln = 0xffffffffu, split = 0u, ln2 = 0u;
+            if (after && v != 0u) {
+                const int c0 = __builtin_ctzll(after);
+                const uint32_t end0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, c0);
+                const uint32_t first0 = end0 - (uint32_t)__builtin_amdgcn_readlane((int)cnt, c0);
+                const unsigned long long rest = after & ~(1ull << c0);
+                if (pos + v <= end0) {
+                    ln = (b * a.pieces + (uint32_t)c0) * a.src_stride + (pos - first0);
+                    split = v;
+                } else if (rest) {
+                    const int c1 = __builtin_ctzll(rest);
+                    const uint32_t end1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, c1);
+                    if (pos + v <= end1) {
+                        ln = (b * a.pieces + (uint32_t)c0) * a.src_stride + (pos - first0);
+                        split = end0 - pos;                                             // tile positions below it: first stretch
+                        ln2 = (b * a.pieces + (uint32_t)c1) * a.src_stride - split;     // + tile position = index of the second
+                    }
+                }
+            }
+            if (l == 0) {
+                s_misc[1] = pos;
+                s_misc[2] = v;
+                s_misc[3] = ln;
+                s_misc[4] = split;
+                s_misc[5] = ln2;
+            }
+        }
+        __syncthreads();
+        base = s_misc[1];
+        valid = s_misc[2];
+        lin = s_misc[3];
+        if (valid == 0u) return;   // a tile beyond the bucket's keys
+        cursor_base = b * 256u;
+    } else if (a.src_counts == nullptr) {
         base = blockIdx.x * (uint32_t)C::TILE;
         const uint32_t left = a.n - base;
         valid = left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE;
@@ -944,6 +1030,7 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
         place = msd2_placement(a.sample);
         start_bit = place.top - 8 * a.which_digit;
     }
+    if constexpr (PASS == 3) start_bit = (int)a.place->top - 16;
     uint32_t* my_wcnt = s_wcnt + w * BINS;
     const IO io{a.src, a.dst};
     const bool scaled = dst_fits32<IO>(a.dst_total);
@@ -951,8 +1038,33 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
     // ---- load, wave-striped; slots beyond `valid` are all-ones pads (digit 255, highest tile positions, never stored) ----
     const uint32_t wbase = (uint32_t)(w * 64 * K + lane);
     E e[K];
-    {
-        const typename IO::Cursor p = io.cursor((size_t)base + wbase);
+    if (PASS == 3 && lin == 0xffffffffu) {
+        // the tile runs across sub-slabs: position in the bucket -> sub-slab, found once for the lane's first element, then
+        // carried along (positions rise).  The tables sit in the s_goff area (written again only after the ranking's barrier).
+        const uint32_t* __restrict__ s_end = s_goff;
+        const uint32_t* __restrict__ s_adj = s_goff + 32;
+        const uint32_t q0 = base + wbase;
+        uint32_t c = 0u;
+        for (uint32_t i = 0; i < a.pieces; ++i) c += (q0 >= s_end[i]) ? 1u : 0u;
+        const int rem = (int)valid - (int)wbase;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t q = q0 + (uint32_t)(j * 64);
+            while (c < 31u && q >= s_end[c]) ++c;
+            e[j] = (j * 64 < rem) ? a.src[(size_t)(q + s_adj[c])] : ~E(0);
+        }
+    } else if (PASS == 3 && reinterpret_cast<const uint32_t*>(smem + C::OFF_MISC)[4] < valid) {
+        // two stretches: tile positions below `split` come from the first sub-slab, the others from the next one
+        const uint32_t split = reinterpret_cast<const uint32_t*>(smem + C::OFF_MISC)[4];
+        const uint32_t ln2 = reinterpret_cast<const uint32_t*>(smem + C::OFF_MISC)[5];
+        const int rem = (int)valid - (int)wbase;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t i = wbase + (uint32_t)(j * 64);
+            e[j] = (j * 64 < rem) ? a.src[(size_t)((i < split ? lin : ln2) + i)] : ~E(0);
+        }
+    } else {
+        const typename IO::Cursor p = io.cursor((size_t)(PASS == 3 ? lin : base) + wbase);
         if (valid == (uint32_t)C::TILE) {
 #pragma unroll
             for (int j = 0; j < K; ++j) e[j] = p.at(j * 64);
@@ -1151,23 +1263,6 @@ __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, 
 //           keys-only form; the safety net is the same cooperative LSD sort.
 // Tickets give tile indices in arrival order, so a tile only ever waits for tiles that already run.
 // ------------------------------------------------------------------------------------------
-struct StablePlace {   // written by msd2s_prep_kernel
-    uint32_t top;      // one past the highest key bit (below sort_bits) in which two sampled keys differ (>= 16)
-    uint32_t low_bits; // top - 16: what the finish sorts
-    uint32_t sort_bits;
-    uint32_t pad;
-    unsigned long long prefix;   // (key & mask(sort_bits)) >> top of every key (top < key bits)
-    unsigned long long kmask;    // mask(sort_bits)
-};
-
-// The key of an element: the whole element (u32 keys; u64 keys: KEY64), or the low dword of a {key, value} pair.
-template <bool KEY64, typename E>
-__device__ __forceinline__ unsigned long long key_of(E e)
-{
-    if constexpr (KEY64) return (unsigned long long)e;
-    else return (unsigned long long)(uint32_t)e;
-}
-
 // one workgroup: sample 1024 keys -> digit placement; clear the tickets of both passes.  Only the low sort_bits bits of a key take
 // part in the sort (Pprims.cpp:357: the passes cover bits [0, sortBits)); the digits are placed inside them.
 template <typename E, bool KEY64>
@@ -1509,7 +1604,7 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
                                                             uint32_t* __restrict__ mode, uint32_t* host_mode, uint32_t n,
                                                             const StablePlace* __restrict__ place, E* data, E* tmp,
                                                             uint32_t* __restrict__ ctable, uint32_t* fault, uint32_t* soa_keys,
-                                                            uint32_t* soa_vals)
+                                                            uint32_t* soa_vals, uint32_t* cursors_b /* hybrid form, else nullptr */)
 {
     __shared__ uint32_t s_wsum[256 / 64 + 1];
     __shared__ uint32_t s_misc[4];
@@ -1537,7 +1632,13 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
     }
     __syncthreads();
     const uint32_t tiles_b = s_misc[1];
-    const uint32_t cb = tiles_b ? (status_b[((size_t)b * rows_per_chain_b + tiles_b - 1u) * 256u + (uint32_t)t] & kValMask) : 0u;
+    uint32_t cb;
+    if (cursors_b) {   // hybrid form: the second pass placed its runs with cursors [bucket][digit]; they go back to zero here
+        cb = __hip_atomic_load(cursors_b + b * 256u + (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cursors_b + b * 256u + (uint32_t)t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        cb = tiles_b ? (status_b[((size_t)b * rows_per_chain_b + tiles_b - 1u) * 256u + (uint32_t)t] & kValMask) : 0u;
+    }
     const uint32_t exb = block_excl_scan_u32<256>(cb, s_wsum, nullptr);
     seg_cnt[b * 256u + (uint32_t)t] = cb;
     seg_off[b * 256u + (uint32_t)t] = s_misc[0] + exb;

@@ -1362,6 +1362,9 @@ def test_size_classes_run_the_kernels_they_claim(dev):
             (300007, {"sort.mid": 3}, {"mid_prep_u32", "onesweep_u32_8b", "segment_sort_u32"}),
             ((1 << 22) + 5, {"sort.msd2": 2}, LARGE_U32),
             ((1 << 22) + 5, {"sort.msd2": 3}, {"msd2s_prep", "msd2s_pass1_u32", "msd2s_pass2_u32", "msd2s_offsets", "segment_sort_wave_u32"}),
+            ((1 << 22) + 5, {"sort.msd2": 5}, {"msd2s_prep", "msd2s_pass1_u32", "msd2h_pass2_u32", "msd2s_offsets", "segment_sort_wave_u32"}),
+            (3000001, {"sort.msd2": 5}, {"msd2s_prep", "msd2s_pass1_u32", "msd2h_pass2_u32", "msd2s_offsets", "segment_sort_wave_u32"}),
+            ((1 << 22) + 5, {"sort.msd2": 4}, LARGE_U32),
             ((1 << 22) + 5, {"sort.msd2": 0}, {"count_u32_8b", "scan_table", "scatter_u32_8b"}),
             ((1 << 23) + 5, {"sort.msd2": 0}, {"os_hist_u32", "os_hist_reduce", "os_tables", "onesweep_u32_8b"}),
         ]
@@ -1464,9 +1467,16 @@ def test_u64_keys_stable_passes_binning_finish_and_its_handover(dev):
         got, prof = _profiled(dev, lambda: gpu_sort_u64(dev, p, k))
         assert set(prof) == LARGE_U64_BIN, prof
         assert np.array_equal(got, oracle.sort_u64(k))
-        dev.setParam("sort.msd2", 2)        # forced, forms as the automatic choice takes them: 32 Mi + 3 keys -> stable passes
+        k = oracle.keys_u64((3 << 24) + 3, seed=7)
+        dev.setParam("sort.msd2", 2)        # forced, forms as the automatic choice takes them: 48 Mi + 3 keys -> stable passes
         got, prof = _profiled(dev, lambda: gpu_sort_u64(dev, p, k))
         assert set(prof) == LARGE_U64_BIN, prof
+        assert np.array_equal(got, oracle.sort_u64(k))
+        dev.setParam("sort.msd2", 5)        # hybrid: stable first pass, cursor-placed second pass over its sub-slabs
+        got, prof = _profiled(dev, lambda: gpu_sort_u64(dev, p, k))
+        assert {"msd2s_pass1_u64", "msd2h_pass2_u64", "segment_sort_bin_u64"} <= set(prof), prof
+        assert np.array_equal(got, oracle.sort_u64(k))
+        dev.setParam("sort.msd2", 2)
         k = oracle.keys_u64((1 << 24) + 3, seed=8)   # ... 16 Mi + 3 keys -> cursor passes, LSD finish
         got, prof = _profiled(dev, lambda: gpu_sort_u64(dev, p, k))
         assert set(prof) == {"msd2_sample", "msd2_pass1_u64", "msd2_pass2_u64", "msd2_offsets", "segment_sort_wave_e64"}, prof
@@ -1501,4 +1511,43 @@ def test_small_partition_keeps_off_the_paths_with_a_grid_barrier(dev):
     finally:
         dev.setParam("debug.resident_wgs", 0)
         assert dev.getParam("debug.resident_wgs") == real
+        p.close()
+
+
+def test_hybrid_form_whole_u32_keys(dev):
+    """Whole u32 keys through the hybrid form ("sort.msd2" = 5; the automatic choice from 96 Mi keys): stable first pass into
+    sub-slabs, cursor-placed second pass over buckets made of those sub-slabs (tiles inside one sub-slab, across two, across
+    many), 16-bit second slab.  Friendly, narrow, skewed (safety net) and outlier keys; bit-exact against the oracle."""
+    dev.setParam("sort.msd2", 5)
+    p = Pprims()
+    try:
+        for n in ((1 << 20) + 77, 2500000, (1 << 24) + 5, (1 << 26) + 999999):
+            k = oracle.keys_u32(n, seed=n & 0xff)
+            assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), ("uniform", n)
+        n = (1 << 23) + 77
+        u = oracle.keys_u32(n, seed=19)
+        cases = {
+            "one eighth of the key range": (u >> np.uint32(3)) | np.uint32(0xa0000000),
+            "below 2^20": u >> np.uint32(12),
+            "below 2^16 (nothing left for the finish)": u >> np.uint32(16),
+            "first half of the input in few buckets (sub-slabs of very different sizes)":
+                np.where(np.arange(n) < n // 2, u & np.uint32(0x07ffffff), u).astype(np.uint32),
+            "one heavy top byte (safety net)": np.where(np.arange(n) % 10 != 0, u >> np.uint32(8), u).astype(np.uint32),
+            "all equal (safety net)": np.full(n, 0xdeadbeef, dtype=np.uint32),
+            "sorted": np.sort(u),
+        }
+        for nm, k in cases.items():
+            assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), nm
+        k = (u >> np.uint32(8)).copy()
+        k[12345] = 0xf0000001
+        assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), "outlier above the sampled range"
+        DeviceUtils.waitForCompletion(dev)
+        dev.setParam("sort.msd2", 2)   # the automatic forms: 128 Mi + 5 keys take the hybrid form
+        n = (1 << 27) + 5
+        k = oracle.keys_u32(n, seed=55)
+        got, prof = _profiled(dev, lambda: gpu_sort_u32(dev, p, k))
+        assert {"msd2s_pass1_u32", "msd2h_pass2_u32", "segment_sort_wave_u32"} <= set(prof), prof
+        assert np.array_equal(got, oracle.sort_u32(k))
+    finally:
+        dev.setParam("sort.msd2", 1)
         p.close()
