@@ -132,14 +132,25 @@ int adlhip_unmap(adlhip_device* dev, void* dptr, void* hptr, size_t bytes);
  * Pprims.cpp:226-232, :332) and m_u32WorkBuffer[1] (histogram table, :229-230, :333-337).
  *   *tmp_bytes  : second data buffer, n elements
  *   *work_bytes : control scratch (digit tables / tile status words) and, for the sizes the large sort takes
- *                 ("sort.msd2": full-key sorts of more than 1 Mi elements), its bucket and segment slabs -- about
- *                 2.3 - 3.3 x n elements (64 Mi u32 keys: 0.61 GB; 64 Mi pairs: 1.7 GB; 256 Mi u64 keys: 5.9 GB).  The value
+ *                 ("sort.msd2": sorts of more than 1 Mi elements), its bucket and segment slabs -- about 1.5 x n elements
+ *                 for whole u32 keys from 16 Mi keys up (their 16-bit second slab then lives in d_tmp; 64 Mi keys: 0.41 GB),
+ *                 3 x n elements otherwise (64 Mi pairs: 1.7 GB; 256 Mi u64 keys: 6.6 GB).  The value
  *                 suffices for EVERY n' <= n with the current knobs (the need of a single n is not monotone:
  *                 smaller inputs use smaller tiles and so more status rows), so a caller may size its scratch
  *                 once for its largest batch; changing "sort.tile", "sort.digit_bits" or "sort.algo" later can
  *                 raise the requirement (the sort entry points re-check and fail loudly). */
 int adlhip_radix_sort_scratch_bytes(adlhip_device* dev, int elem_kind, size_t n,
                                     size_t* tmp_bytes, size_t* work_bytes);
+
+/* The same for a sort on `sort_bits` bits, at one of two levels:
+ *   level 0: the minimum -- the reference's own contract (Pprims.cpp:332-337: the n-element partner array and a digit table of
+ *            a few KiB).  Every sort entry point accepts a work buffer of this size; the sort then runs the per-digit
+ *            three-kernel passes (64 Mi u32 keys: 75 instead of 164 Gkeys/s).
+ *   level 1: full speed -- what adlhip_radix_sort_scratch_bytes reports for whole keys.  A sort on fewer bits than the key has
+ *            takes the stable form of the large sort, whose second slab cannot shrink to 16 bits per key, and so needs more.
+ * With a work buffer between the two, every path checks its own need and the sort takes the fastest one that fits. */
+int adlhip_radix_sort_scratch_bytes_for(adlhip_device* dev, int elem_kind, size_t n, int sort_bits, int level,
+                                        size_t* tmp_bytes, size_t* work_bytes);
 
 /* Pprims::radixSort(const Device*, const Buffer<u32>& inout, int n, int sortBits=32)
  * -- Tahoe/ParallelPrimitives/Pprims.h:41, Pprims.cpp:304-406.

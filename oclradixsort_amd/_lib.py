@@ -57,6 +57,7 @@ SIGNATURES = {
     "adlhip_map": (_I, [_VP, _VP, _SZ, c_void_pp]),
     "adlhip_unmap": (_I, [_VP, _VP, _VP, _SZ]),
     "adlhip_radix_sort_scratch_bytes": (_I, [_VP, _I, _SZ, c_size_p, c_size_p]),
+    "adlhip_radix_sort_scratch_bytes_for": (_I, [_VP, _I, _SZ, _I, _I, c_size_p, c_size_p]),
     "adlhip_radix_sort_u32": (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
     "adlhip_radix_sort_kv32": (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
     "adlhip_radix_sort_soa32": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I]),

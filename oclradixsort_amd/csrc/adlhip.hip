@@ -920,9 +920,16 @@ constexpr size_t kMsd2MaxU32 = size_t(280) << 20;                  // mean segme
 constexpr size_t kMsd2MaxU64 = (size_t(1) << 28) + (size_t(1) << 22);   // mean segment 4160
 // the wave-per-segment finish's tiles: 64 * 20, 64 * 40, 64 * 80 elements
 
+// from here the 16-bit second slab of whole u32 keys always fits the caller's n-element scratch array (1.5 x the mean + 72 per
+// segment <= 2 x the mean); one fixed threshold keeps the work requirement piecewise monotone in n (sort_work_bytes' edges)
+constexpr size_t kSlabInTmpMin = size_t(16) << 20;
+
 struct Msd2Layout {
     size_t off_mode, off_cnt, off_off, off_hard, off_coop, off_slab_a, off_slab_b, total;
-    uint32_t stride_a, stride_b, tiles_per_bucket;
+    uint32_t stride_a, stride_b, tier_b, tiles_per_bucket;
+    bool slab_b_in_tmp;   // the second slab fits the caller's n-element scratch array (u32 keys from ~40 Mi keys: 16-bit elements,
+                          // 1.5 x the mean per segment = 0.75 n * 4 bytes); the safety net, which needs that array as its partner,
+                          // only ever runs when the slabs' contents are void
 };
 
 // slab of a segment = the smallest of the finish's tiles that holds its mean + 7.5 standard deviations of a uniform key
@@ -932,7 +939,8 @@ struct Msd2Layout {
 // density varied by 20 % over the key range already went to the safety net; 1536 takes ~45 % and costs nothing measurable
 // (finish 118.0 vs 118.3 us at 64 Mi keys: five workgroups of four waves per CU instead of three of eight)
 constexpr uint32_t kMsd2Stride0 = 1536;
-uint32_t msd2_stride_b(size_t n)
+// tile of the finish for n elements: 1280 / 1536 / 2560 / 5120 (what a wave -- or a workgroup of the binning finish -- holds)
+uint32_t msd2_tier_b(size_t n)
 {
     const size_t mean = (n + 65535) / 65536;
     size_t sd = 1;
@@ -940,6 +948,16 @@ uint32_t msd2_stride_b(size_t n)
     const size_t need = mean + (15 * sd + 1) / 2;
     // (the tiers' bounds on the mean stay as they were; up to a mean of ~640 the 1280-element tile already leaves 1.5 x)
     return need <= 832 ? 1280u : need <= 1280 ? kMsd2Stride0 : need <= 2560 ? 2560u : 5120u;
+}
+// elements between two segment slabs: the mean + 50 % (or + 7.5 sd where that is more), at most the finish's tile.  (Round 2 spaced
+// the slabs by the tile whatever n was: 168 MB of second slab for 2 Mi keys.)
+uint32_t msd2_stride_b(size_t n)
+{
+    const size_t mean = (n + 65535) / 65536;
+    size_t sd = 1;
+    while (sd * sd < mean) ++sd;
+    const size_t want = align_up(std::max(mean + mean / 2, mean + (15 * sd + 1) / 2) + 8, 64);
+    return (uint32_t)std::min<size_t>(want, msd2_tier_b(n));
 }
 
 Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
@@ -950,6 +968,7 @@ Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
     // varies by up to ~45 % over the key range stay on this path (with + 3 % any mild skew went to the safety net)
     L.stride_a = (uint32_t)align_up(n / 256 + n / 512 + 4096, 64);
     L.stride_b = msd2_stride_b(n);
+    L.tier_b = msd2_tier_b(n);
     L.tiles_per_bucket = (L.stride_a + tile - 1) / tile;
     L.off_mode = 0;
     L.off_cnt = L.off_mode + 256;
@@ -958,7 +977,9 @@ Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
     L.off_coop = L.off_hard + 65536 * 4;                                     // safety net: table [256][256] + 256 totals
     L.off_slab_a = align_up(L.off_coop + (size_t)256 * 256 * 4 + 1024, 256);
     L.off_slab_b = align_up(L.off_slab_a + (size_t)256 * L.stride_a * elem_bytes, 256);
-    L.total = L.off_slab_b + (size_t)65536 * L.stride_b * (elem_bytes == 4 ? 2 : elem_bytes);   // u32 keys: 16-bit second slab
+    const size_t slab_b_bytes = (size_t)65536 * L.stride_b * (elem_bytes == 4 ? 2 : elem_bytes);   // u32 keys: 16-bit second slab
+    L.slab_b_in_tmp = elem_bytes == 4 && n >= kSlabInTmpMin && slab_b_bytes <= n * elem_bytes;
+    L.total = L.off_slab_b + (L.slab_b_in_tmp ? 0 : slab_b_bytes);
     return L;
 }
 
@@ -1011,7 +1032,7 @@ int msd2_probe(adlhip_device* d, const void* keys, size_t elem_bytes, int key_bi
 
 template <typename E, typename S, bool SOA = false>
 int launch_large_finish(adlhip_device* d, const E* slab_b, E* out, uint32_t* out_vals, uint32_t* seg_off, uint32_t* seg_cnt, uint32_t stride_b,
-                        uint32_t* mode, uint32_t* hard, int low_bits_max, bool bin);
+                        uint32_t tier_b, uint32_t* mode, uint32_t* hard, int low_bits_max, bool bin);
 bool use_bin_finish(const adlhip_device* d, size_t elem_bytes, bool key64, size_t n, bool whole_keys);
 
 template <typename E>
@@ -1036,7 +1057,7 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     uint32_t* seg_cnt = reinterpret_cast<uint32_t*>(wb + L.off_cnt);
     uint32_t* seg_off = reinterpret_cast<uint32_t*>(wb + L.off_off);
     E* slab_a = reinterpret_cast<E*>(wb + L.off_slab_a);
-    E* slab_b = reinterpret_cast<E*>(wb + L.off_slab_b);
+    E* slab_b = L.slab_b_in_tmp ? tmp : reinterpret_cast<E*>(wb + L.off_slab_b);
     using CT = adlhip::TileCfg<E, 8, 512, K>;
     auto kern = adlhip::msd_bucket_scatter_kernel<E, 512, K, 1>;
     auto kern2 = adlhip::msd_bucket_scatter_kernel<E, 512, K, 2>;
@@ -1080,7 +1101,7 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     // the finish sorts the bits below the second digit (the offsets kernel has published how many)
     using S = typename std::conditional<sizeof(E) == 4, uint16_t, E>::type;   // what pass 2 wrote
     uint32_t* hard = reinterpret_cast<uint32_t*>(wb + L.off_hard);
-    return launch_large_finish<E, S>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, mode, hard, KEY_BITS - 16,
+    return launch_large_finish<E, S>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, L.tier_b, mode, hard, KEY_BITS - 16,
                                      use_bin_finish(d, sizeof(E), sizeof(E) == 8, n, true));
 }
 
@@ -1092,11 +1113,14 @@ constexpr uint32_t msd2s_tile(size_t elem_bytes) { return elem_bytes == 8 ? 8192
 
 struct Msd2sLayout {
     size_t off_mode, off_place, off_cnt, off_off, off_hard, off_coop, off_tickets, off_status_a, off_status_b, off_slab_a, off_slab_b, total;
-    uint32_t pieces, slice, rows_a, rows_b, stride_a, stride_b, ticket_words;
+    uint32_t pieces, slice, rows_a, rows_b, stride_a, stride_b, tier_b, ticket_words;
     size_t status_bytes_a, status_bytes_b;
+    bool slab_b_in_tmp;
 };
 
-Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8)
+// slab16: whole u32 keys -- the second slab holds their low 16 bits and, from 16 Mi keys, sits in the caller's n-element scratch
+// array (see Msd2Layout::slab_b_in_tmp)
+Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8, bool slab16 = false)
 {
     Msd2sLayout L;
     const uint32_t kMsd2sTile = msd2s_tile(elem_bytes);
@@ -1124,6 +1148,7 @@ Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8)
     // the most tiles a bucket can have: pass B's tiles run across the sub-slabs, and a sub-slab holds at most its stride
     L.rows_b = (uint32_t)(((size_t)L.pieces * L.stride_a + kMsd2sTile - 1) / kMsd2sTile);
     L.stride_b = msd2_stride_b(n);
+    L.tier_b = msd2_tier_b(n);
     L.ticket_words = (32 + 256) * adlhip::kTicketStride;
     L.status_bytes_a = (size_t)L.pieces * L.rows_a * 1024;
     L.status_bytes_b = (size_t)256 * L.rows_b * 1024;
@@ -1146,7 +1171,9 @@ Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8)
     L.off_status_b = L.off_status_a + rows_a_bound * 1024;
     L.off_slab_a = align_up(L.off_status_b + 256 * rows_b_bound * 1024, 256);
     L.off_slab_b = align_up(L.off_slab_a + 256 * bucket_bound * elem_bytes, 256);
-    L.total = L.off_slab_b + (size_t)65536 * L.stride_b * elem_bytes;
+    const size_t slab_b_bytes = (size_t)65536 * L.stride_b * (slab16 ? 2 : elem_bytes);
+    L.slab_b_in_tmp = slab16 && n >= kSlabInTmpMin && slab_b_bytes <= n * elem_bytes;
+    L.total = L.off_slab_b + (L.slab_b_in_tmp ? 0 : slab_b_bytes);
     if ((size_t)L.pieces * L.rows_a > rows_a_bound || L.rows_b > rows_b_bound || (size_t)L.pieces * L.stride_a > bucket_bound)
         L.total = 0;   // cannot happen; msd2s_sort refuses
     return L;
@@ -1183,26 +1210,27 @@ LargeForm large_sort_form(const adlhip_device* d, size_t elem_bytes, bool keys, 
 // LSD finish's list form for what it handed over) or the wave-per-segment LSD finish.  S = what the second slab holds.
 template <typename E, typename S, bool SOA>
 int launch_large_finish(adlhip_device* d, const E* slab_b, E* out, uint32_t* out_vals, uint32_t* seg_off, uint32_t* seg_cnt, uint32_t stride_b,
-                        uint32_t* mode, uint32_t* hard, int low_bits_max, bool bin)
+                        uint32_t tier_b, uint32_t* mode, uint32_t* hard, int low_bits_max, bool bin)
 {
+    // tier_b = the tile that holds a segment (msd2_tier_b); stride_b <= tier_b = the spacing of the segment slabs
     const uint32_t* lowb = mode + adlhip::kDynLowBits;
     if constexpr (!SOA) {
         if (bin) {
             const S* sb = reinterpret_cast<const S*>(slab_b);
             int rc;
-            if (stride_b <= kMsd2Stride0) rc = launch_bin_segment_sort<E, S, 256, 6, 11>(d, sb, out, seg_off, seg_cnt, stride_b, mode, hard);
-            else if (stride_b == 2560) rc = launch_bin_segment_sort<E, S, 256, 10, 12>(d, sb, out, seg_off, seg_cnt, stride_b, mode, hard);
+            if (tier_b <= kMsd2Stride0) rc = launch_bin_segment_sort<E, S, 256, 6, 11>(d, sb, out, seg_off, seg_cnt, stride_b, mode, hard);
+            else if (tier_b == 2560) rc = launch_bin_segment_sort<E, S, 256, 10, 12>(d, sb, out, seg_off, seg_cnt, stride_b, mode, hard);
             else rc = launch_bin_segment_sort<E, S, 512, 10, 12>(d, sb, out, seg_off, seg_cnt, stride_b, mode, hard);
             if (rc) return rc;
             const uint32_t* hc = mode + adlhip::kDynHardCnt;
-            if (stride_b <= kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc);
-            if (stride_b == 2560) return launch_wave_segment_sort<E, 40, S>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc);
+            if (tier_b <= kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc);
+            if (tier_b == 2560) return launch_wave_segment_sort<E, 40, S>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc);
             return launch_wave_segment_sort<E, 80, S>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc);
         }
     }
-    if (stride_b == 1280) return launch_wave_segment_sort<E, 20, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
-    if (stride_b == kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
-    if (stride_b == 2560) return launch_wave_segment_sort<E, 40, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
+    if (tier_b == 1280) return launch_wave_segment_sort<E, 20, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
+    if (tier_b == kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
+    if (tier_b == 2560) return launch_wave_segment_sort<E, 40, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
     return launch_wave_segment_sort<E, 80, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
 }
 
@@ -1242,7 +1270,7 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
     uint32_t* flag = d->d_msd2 + 8192 + 65536;
     uint32_t* done = flag + 1;
     uint32_t* bar = flag + 2;
-    const Msd2sLayout L = msd2s_layout(n, sizeof(E));
+    const Msd2sLayout L = msd2s_layout(n, sizeof(E), k32 && whole);
     if (L.total == 0) return fail("internal: layout bounds of the stable large sort");
     char* wb = reinterpret_cast<char*>(work);
     uint32_t* mode = reinterpret_cast<uint32_t*>(wb + L.off_mode);
@@ -1254,7 +1282,7 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
     uint32_t* status_a = reinterpret_cast<uint32_t*>(wb + L.off_status_a);
     uint32_t* status_b = reinterpret_cast<uint32_t*>(wb + L.off_status_b);
     E* slab_a = reinterpret_cast<E*>(wb + L.off_slab_a);
-    E* slab_b = reinterpret_cast<E*>(wb + L.off_slab_b);
+    E* slab_b = L.slab_b_in_tmp ? tmp : reinterpret_cast<E*>(wb + L.off_slab_b);
     using CT = adlhip::TileCfg<E, 8, 512, K>;
     static_assert(CT::TILE == (int)msd2s_tile(sizeof(E)), "layout and kernel agree on the tile");
     auto kern = adlhip::msd_lookback_scatter_kernel<E, 512, K, KEY64>;
@@ -1325,51 +1353,77 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
     const int low_max = sort_bits - 16;
     const bool bin = use_bin_finish(d, sizeof(E), KEY64, n, whole);
     if constexpr (k32) {
-        if (slab16) return launch_large_finish<E, uint16_t>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, mode, hard, low_max, bin);
-        return launch_large_finish<E, E>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, mode, hard, low_max, false);
+        if (slab16) return launch_large_finish<E, uint16_t>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, L.tier_b, mode, hard, low_max, bin);
+        return launch_large_finish<E, E>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, L.tier_b, mode, hard, low_max, false);
     } else {
         if (soa_keys)   // the finish writes keys and values to their own arrays
-            return launch_large_finish<E, E, true>(d, slab_b, reinterpret_cast<E*>(soa_keys), soa_vals, seg_off, seg_cnt, L.stride_b, mode, hard,
-                                                   low_max, false);
-        return launch_large_finish<E, E>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, mode, hard, low_max, bin);
+            return launch_large_finish<E, E, true>(d, slab_b, reinterpret_cast<E*>(soa_keys), soa_vals, seg_off, seg_cnt, L.stride_b, L.tier_b, mode,
+                                                   hard, low_max, false);
+        return launch_large_finish<E, E>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, L.tier_b, mode, hard, low_max, bin);
     }
 }
 
-size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n)
+// what the large sort's form for this sort needs (0: the sort does not take the large sort)
+size_t large_work_bytes(LargeForm form, size_t elem_bytes, size_t n, bool whole)
+{
+    if (form == kLargeCursor) return msd2_layout(n, elem_bytes).total;
+    if (form == kLargeStable || form == kLargeHybrid) return msd2s_layout(n, elem_bytes, elem_bytes == 4 && whole).total;
+    return 0;
+}
+
+// Work bytes with which a sort of n elements on sort_bits bits runs at full speed (level 1), or runs at all (level 0: the
+// per-digit three-kernel passes -- the reference's own contract: a table of a few KiB beside the n-element partner array,
+// Pprims.cpp:332-337).  With anything in between, every path checks its own need and the sort takes the fastest one that fits.
+size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n, int sort_bits, int level)
 {
     const size_t a = work_bytes_three_kernel(d, n);
+    if (level == 0) return a;
     size_t b;
     if (elem_kind == ADLHIP_ELEM_U32) b = onesweep_layout(d, n, max_passes_for(d, 32), buf_tile<AosBuf<uint32_t>>(d, n)).total;
     else if (elem_kind == ADLHIP_ELEM_SOA32) b = onesweep_layout(d, n, max_passes_for(d, 64), buf_tile<SoaBuf>(d, n)).total;
     else b = onesweep_layout(d, n, max_passes_for(d, 64), buf_tile<AosBuf<uint64_t>>(d, n)).total;   // as onesweep_sort<Buf>()
     const size_t c = n <= kMidMaxU32 ? mid_layout(n).total : mid_layout(kMidMaxU32).total;   // mid-size sort (monotone in n)
-    size_t e = 0;   // large keys-only sort: slabs behind the one-sweep layout (monotone in n up to its limit)
-    if (elem_kind == ADLHIP_ELEM_U32 && n > kMsd2Min)
-        e = std::max(msd2_layout(std::min(n, kMsd2MaxU32), 4).total, msd2s_layout(std::min(n, kMsd2sMax), 4).total);
-    if (elem_kind == ADLHIP_ELEM_U64 && n > kMsd2Min)
-        e = std::max(msd2_layout(std::min(n, kMsd2MaxU64), 8).total, msd2s_layout(std::min(n, kMsd2sMax), 8).total);
-    if ((elem_kind == ADLHIP_ELEM_KV32 || elem_kind == ADLHIP_ELEM_SOA32) && n > kMsd2Min) e = msd2s_layout(std::min(n, kMsd2sMax)).total;
+    // the large sort: every form this (kind, n, sort_bits) can take, whatever "sort.msd2" says now (the knob may change between
+    // the query and the sort)
+    size_t e = 0;
+    const size_t eb = elem_kind == ADLHIP_ELEM_U32 ? 4 : 8;
+    const int max_bits = elem_kind == ADLHIP_ELEM_U64 ? 64 : 32;
+    const bool whole = sort_bits == max_bits;
+    const bool keys = elem_kind == ADLHIP_ELEM_U32 || elem_kind == ADLHIP_ELEM_U64;
+    if (n > kMsd2Min && sort_bits >= 16) {
+        if (n <= kMsd2sMax) e = msd2s_layout(n, eb, eb == 4 && whole).total;
+        if (keys && whole && n <= (eb == 4 ? kMsd2MaxU32 : kMsd2MaxU64)) e = std::max(e, msd2_layout(n, eb).total);
+    }
     return std::max(std::max(a, b), std::max(c, e));
 }
 
 // Work bytes that suffice for EVERY n' <= n with the current knobs: the requirement of one n is not monotone (a smaller
-// input selects a smaller tile, which needs more status rows), so a caller that sizes its scratch once for its largest
-// batch must get the maximum over the sizes at which the automatic tile choice changes (effective_variant: 8 and 24 MiB
-// of data).  Changing "sort.tile", "sort.digit_bits" or "sort.algo" afterwards can raise the requirement.
-size_t sort_work_bytes(const adlhip_device* d, int elem_kind, size_t n)
+// input selects a smaller tile, which needs more status rows; from 16 Mi keys the second slab of whole u32 keys moves into the
+// partner array), so a caller that sizes its scratch once for its largest batch must get the maximum over the sizes at which
+// such a choice changes.  Changing "sort.tile", "sort.digit_bits" or "sort.algo" afterwards can raise the requirement.
+size_t sort_work_bytes(const adlhip_device* d, int elem_kind, size_t n, int sort_bits, int level)
 {
     const size_t esz = (elem_kind == ADLHIP_ELEM_U32) ? 4 : 8;
-    size_t need = sort_work_bytes_at(d, elem_kind, n);
-    for (size_t edge : {(size_t(8) << 20) / esz, (size_t(24) << 20) / esz - 1})
-        if (edge < n) need = std::max(need, sort_work_bytes_at(d, elem_kind, edge));
+    size_t need = sort_work_bytes_at(d, elem_kind, n, sort_bits, level);
+    for (size_t edge : {(size_t(8) << 20) / esz, (size_t(24) << 20) / esz - 1, kSlabInTmpMin - 1, kMsd2sMax, kMsd2MaxU32})
+        if (edge < n) need = std::max(need, sort_work_bytes_at(d, elem_kind, edge, sort_bits, level));
     return need;
 }
 
 // choose the path (shared by the AoS and SoA entry points)
 template <typename Buf>
-int run_sort(adlhip_device* d, Buf data, Buf tmp, void* work, size_t n, const std::vector<PassPlan>& plan)
+int run_sort(adlhip_device* d, Buf data, Buf tmp, void* work, size_t work_bytes, size_t n, const std::vector<PassPlan>& plan)
 {
     const bool seven = !plan.empty() && plan[0].nbits == 7;   // 7-bit digits exist in the one-sweep pass only
+    {   // a work buffer sized by the reference's contract (level 0) holds the three-kernel pass's table and nothing else
+        const size_t os = onesweep_layout(d, n, max_passes_for(d, Buf::kElemBytes == 4 && !Buf::kSoa ? 32 : 64), buf_tile<Buf>(d, n)).total;
+        if (work_bytes < os) {
+            if (seven || d->sort_algo == 0)
+                return fail("work buffer too small for the one-sweep path the knobs ask for: %zu < %zu (adlhip_radix_sort_scratch_bytes)",
+                            work_bytes, os);
+            return three_kernel_sort<Buf>(d, data, tmp, work, n, plan);
+        }
+    }
     if (d->sort_algo < 0 && !seven) {   // automatic choice by size (profiles/r1_ncurve.txt)
         // the one-sweep path has more fixed cost (histogram, tables) and wins from ~24 MiB of data (fresh random keys,
         // profiles/r1_ncurve.txt: 4Mi u32 keys 78 vs 88 us, 8Mi 124 vs 117 us, 16Mi 224 vs 174 us)
@@ -1393,8 +1447,10 @@ int check_sort_args(adlhip_device* d, int elem_kind, const void* a, const void* 
     if (!a || !b || !work) return fail("null buffer passed to radix sort");
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15u)
         return fail("sort buffers must be 16-byte aligned");
-    const size_t need = sort_work_bytes(d, elem_kind, n);
-    if (work_bytes < need) return fail("work buffer too small: %zu < %zu", work_bytes, need);
+    const size_t need = sort_work_bytes(d, elem_kind, n, sort_bits, 0);
+    if (work_bytes < need)
+        return fail("work buffer too small: %zu < %zu (the minimum; adlhip_radix_sort_scratch_bytes gives the size for full speed)",
+                    work_bytes, need);
     return ADLHIP_SUCCESS;
 }
 
@@ -1407,7 +1463,7 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
     if (n == 0) return ADLHIP_SUCCESS;
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
     if (d->sort_algo < 0 && n <= kSmallMax) return small_sort<E>(d, data, n, plan);   // one workgroup, one launch
-    if (mid_eligible(d, sizeof(E), n, sort_bits, max_bits)) {
+    if (mid_eligible(d, sizeof(E), n, sort_bits, max_bits) && mid_layout(n).total <= work_bytes) {
         const int form = choose_mid_form(d, sizeof(E) == 4);
         if constexpr (sizeof(E) == 4) {
             if (form == 2) return mid_sort_keys(d, data, tmp, work, n);   // two launches
@@ -1415,7 +1471,13 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
         if (form == 3) return mid_sort<E>(d, data, tmp, work, n);         // three launches
     }
     const bool keys = (int)sizeof(E) * 8 == max_bits;
-    const LargeForm form = large_sort_form(d, sizeof(E), keys, n, sort_bits, max_bits);
+    LargeForm form = large_sort_form(d, sizeof(E), keys, n, sort_bits, max_bits);
+    if (form != kLargeNone && large_work_bytes(form, sizeof(E), n, sort_bits == max_bits) > work_bytes) {
+        // the slabs do not fit the caller's work buffer: whole keys may still fit the cursor form (its second slab is smaller)
+        const bool whole = sort_bits == max_bits;
+        form = keys && whole && n <= (sizeof(E) == 4 ? kMsd2MaxU32 : kMsd2MaxU64) &&
+                       large_work_bytes(kLargeCursor, sizeof(E), n, true) <= work_bytes ? kLargeCursor : kLargeNone;
+    }
     if (form != kLargeNone) {
         const Msd2Choice c = msd2_decide(d);
         if (c == kMsd2Use) {
@@ -1430,7 +1492,7 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
         }
         if (c == kMsd2Probe && msd2_probe(d, data, sizeof(E), sort_bits, n)) return ADLHIP_FAILURE;
     }
-    return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, n, plan);
+    return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, work_bytes, n, plan);
 }
 
 // ---- MSB partition (multi-GPU send side) -----------------------------------------------------------
@@ -1889,14 +1951,23 @@ int adlhip_unmap(adlhip_device* d, void* dptr, void* hptr, size_t bytes)
 
 // ---- sort ---------------------------------------------------------------------------------------
 
-int adlhip_radix_sort_scratch_bytes(adlhip_device* d, int elem_kind, size_t n, size_t* tmp_bytes, size_t* work_bytes)
+int adlhip_radix_sort_scratch_bytes_for(adlhip_device* d, int elem_kind, size_t n, int sort_bits, int level, size_t* tmp_bytes,
+                                        size_t* work_bytes)
 {
     if (!d) return fail("null device handle");
     if (elem_kind < ADLHIP_ELEM_U32 || elem_kind > ADLHIP_ELEM_SOA32) return fail("bad element kind %d", elem_kind);
+    const int max_bits = elem_kind == ADLHIP_ELEM_U64 ? 64 : 32;
+    if (sort_bits < 4 || sort_bits > max_bits || (sort_bits & 3)) return fail("sort_bits must be a multiple of 4 in [4,%d], got %d", max_bits, sort_bits);
+    if (level != 0 && level != 1) return fail("level must be 0 (minimum) or 1 (full speed), got %d", level);
     const size_t esz = (elem_kind == ADLHIP_ELEM_U32 || elem_kind == ADLHIP_ELEM_SOA32) ? 4 : 8;   // SoA: per array
     if (tmp_bytes) *tmp_bytes = align_up(n * esz, 256);
-    if (work_bytes) *work_bytes = sort_work_bytes(d, elem_kind, n);
+    if (work_bytes) *work_bytes = sort_work_bytes(d, elem_kind, n, sort_bits, level);
     return ADLHIP_SUCCESS;
+}
+
+int adlhip_radix_sort_scratch_bytes(adlhip_device* d, int elem_kind, size_t n, size_t* tmp_bytes, size_t* work_bytes)
+{
+    return adlhip_radix_sort_scratch_bytes_for(d, elem_kind, n, elem_kind == ADLHIP_ELEM_U64 ? 64 : 32, 1, tmp_bytes, work_bytes);
 }
 
 int adlhip_radix_sort_u32(adlhip_device* d, uint32_t* keys, uint32_t* tmp, void* work, size_t work_bytes, size_t n, int sort_bits)
@@ -1923,13 +1994,13 @@ int adlhip_radix_sort_soa32(adlhip_device* d, uint32_t* keys, uint32_t* vals, ui
     if (!vals || !tmp_vals) return fail("null value buffer passed to radix sort");
     if ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(tmp_vals)) & 15u)
         return fail("sort buffers must be 16-byte aligned");
-    if (large_sort_form(d, 8, false, n, sort_bits, 32) != kLargeNone) {
+    if (large_sort_form(d, 8, false, n, sort_bits, 32) != kLargeNone && large_work_bytes(kLargeStable, 8, n, sort_bits == 32) <= work_bytes) {
         const Msd2Choice c = msd2_decide(d);
         if (c == kMsd2Use) return msd2s_sort<uint64_t, false>(d, nullptr, nullptr, work, n, sort_bits, keys, vals);
         if (c == kMsd2Probe && msd2_probe(d, keys, 4, sort_bits, n)) return ADLHIP_FAILURE;
     }
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
-    return run_sort<SoaBuf>(d, SoaBuf{keys, vals}, SoaBuf{tmp_keys, tmp_vals}, work, n, plan);
+    return run_sort<SoaBuf>(d, SoaBuf{keys, vals}, SoaBuf{tmp_keys, tmp_vals}, work, work_bytes, n, plan);
 }
 
 int adlhip_segment_sort(adlhip_device* d, int elem_kind, void* data, const uint32_t* seg_start, size_t num_segments,

@@ -79,8 +79,9 @@ class Pprims:
         lib = _lib.load()
         tb = ctypes.c_size_t()
         wb = ctypes.c_size_t()
-        check(lib.adlhip_radix_sort_scratch_bytes(device._h, kind, n, ctypes.byref(tb), ctypes.byref(wb)),
-              "adlhip_radix_sort_scratch_bytes")
+        # full-speed scratch for a sort on these bits (level 1; a sort on fewer bits than the key has needs more)
+        check(lib.adlhip_radix_sort_scratch_bytes_for(device._h, kind, n, int(sortBits), 1, ctypes.byref(tb), ctypes.byref(wb)),
+              "adlhip_radix_sort_scratch_bytes_for")
         self._scratch(device, tb.value, wb.value)
         check(fn(device._h, inout.ptr(), self.m_tmp.ptr(), self.m_work.ptr(), self.m_work.getSize(), n, int(sortBits)),
               "radixSort")
@@ -105,8 +106,8 @@ class Pprims:
         lib = _lib.load()
         tb = ctypes.c_size_t()
         wb = ctypes.c_size_t()
-        check(lib.adlhip_radix_sort_scratch_bytes(device._h, ELEM_SOA32, n, ctypes.byref(tb), ctypes.byref(wb)),
-              "adlhip_radix_sort_scratch_bytes")
+        check(lib.adlhip_radix_sort_scratch_bytes_for(device._h, ELEM_SOA32, n, int(sortBits), 1, ctypes.byref(tb), ctypes.byref(wb)),
+              "adlhip_radix_sort_scratch_bytes_for")
         self._scratch(device, 2 * tb.value, wb.value)          # tmp keys + tmp values, back to back
         tmp_k = self.m_tmp.ptr()
         tmp_v = ctypes.c_void_p(self.m_tmp.m_ptr + tb.value) if self.m_tmp.m_ptr else None

@@ -78,7 +78,7 @@ void Pprims::radixSort(const adl::Device* device, const adl::Buffer<u32>& inout,
     }
     ADLASSERT((sortBits & 0x3) == 0);   // Pprims.cpp:330
     size_t tb = 0, wb = 0;
-    const int rcq = adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_U32, (size_t)n, &tb, &wb);   // not inside the assertion: the call has side effects (tb, wb)
+    const int rcq = adlhip_radix_sort_scratch_bytes_for(device->hip(), ADLHIP_ELEM_U32, (size_t)n, sortBits, 1, &tb, &wb);   // not inside the assertion: the call has side effects (tb, wb)
     ADLASSERT(rcq == ADLHIP_SUCCESS);
     reserve(device, tb, wb);
     const int rc = adlhip_radix_sort_u32(device->hip(), inout.m_ptr, (u32*)m_tmp->m_ptr, m_work->m_ptr, (size_t)m_work->getSize(),
@@ -103,7 +103,7 @@ void Pprims::radixSort(const adl::Device* device, const adl::Buffer<uint2>& inou
     }
     ADLASSERT((sortBits & 0x3) == 0);
     size_t tb = 0, wb = 0;
-    const int rcq = adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_KV32, (size_t)n, &tb, &wb);   // not inside the assertion: the call has side effects (tb, wb)
+    const int rcq = adlhip_radix_sort_scratch_bytes_for(device->hip(), ADLHIP_ELEM_KV32, (size_t)n, sortBits, 1, &tb, &wb);   // not inside the assertion: the call has side effects (tb, wb)
     ADLASSERT(rcq == ADLHIP_SUCCESS);
     reserve(device, tb, wb);
     const int rc = adlhip_radix_sort_kv32(device->hip(), inout.m_ptr, m_tmp->m_ptr, m_work->m_ptr, (size_t)m_work->getSize(),
@@ -120,7 +120,7 @@ void Pprims::radixSort(const adl::Device* device, const adl::Buffer<u64>& inout,
     if (!enableSortOnDevice(device)) return;
     ADLASSERT((sortBits & 0x3) == 0);
     size_t tb = 0, wb = 0;
-    const int rcq = adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_U64, (size_t)n, &tb, &wb);   // not inside the assertion: the call has side effects (tb, wb)
+    const int rcq = adlhip_radix_sort_scratch_bytes_for(device->hip(), ADLHIP_ELEM_U64, (size_t)n, sortBits, 1, &tb, &wb);   // not inside the assertion: the call has side effects (tb, wb)
     ADLASSERT(rcq == ADLHIP_SUCCESS);
     reserve(device, tb, wb);
     const int rc = adlhip_radix_sort_u64(device->hip(), (uint64_t*)inout.m_ptr, (uint64_t*)m_tmp->m_ptr, m_work->m_ptr,
@@ -138,7 +138,7 @@ void Pprims::radixSort(const adl::Device* device, const adl::Buffer<u32>& keys, 
     if (!enableSortOnDevice(device)) return;
     ADLASSERT((sortBits & 0x3) == 0);
     size_t tb = 0, wb = 0;
-    const int rcq = adlhip_radix_sort_scratch_bytes(device->hip(), ADLHIP_ELEM_SOA32, (size_t)n, &tb, &wb);   // not inside the assertion: the call has side effects (tb, wb)
+    const int rcq = adlhip_radix_sort_scratch_bytes_for(device->hip(), ADLHIP_ELEM_SOA32, (size_t)n, sortBits, 1, &tb, &wb);   // not inside the assertion: the call has side effects (tb, wb)
     ADLASSERT(rcq == ADLHIP_SUCCESS);
     reserve(device, 2 * tb, wb);   // scratch keys + scratch values, back to back
     const int rc = adlhip_radix_sort_soa32(device->hip(), keys.m_ptr, values.m_ptr, (u32*)m_tmp->m_ptr,

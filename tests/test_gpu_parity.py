@@ -736,9 +736,14 @@ def test_abi_argument_validation(dev):
     assert lib.adlhip_radix_sort_scratch_bytes(dev._h, 0, n, ctypes.byref(tb), ctypes.byref(wb)) == 0
     work = Buffer(dev, wb.value, np.uint8)
     ok = lambda rc: rc == 0
-    # too small a work buffer
-    assert not ok(lib.adlhip_radix_sort_u32(dev._h, keys.ptr(), tmp.ptr(), work.ptr(), wb.value - 1, n, 32))
+    # too small a work buffer: less than the MINIMUM (level 0) is refused; anything from there up sorts (the fastest path that fits)
+    t0, w0 = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.adlhip_radix_sort_scratch_bytes_for(dev._h, 0, n, 32, 0, ctypes.byref(t0), ctypes.byref(w0)) == 0
+    assert not ok(lib.adlhip_radix_sort_u32(dev._h, keys.ptr(), tmp.ptr(), work.ptr(), w0.value - 1, n, 32))
     assert b"work buffer too small" in lib.adlhip_last_error()
+    assert ok(lib.adlhip_radix_sort_u32(dev._h, keys.ptr(), tmp.ptr(), work.ptr(), wb.value - 1, n, 32))
+    assert not ok(lib.adlhip_radix_sort_scratch_bytes_for(dev._h, 0, n, 30, 1, ctypes.byref(t0), ctypes.byref(w0)))   # not a multiple of 4
+    assert not ok(lib.adlhip_radix_sort_scratch_bytes_for(dev._h, 0, n, 32, 2, ctypes.byref(t0), ctypes.byref(w0)))   # no such level
     # null buffers
     assert not ok(lib.adlhip_radix_sort_u32(dev._h, keys.ptr(), None, work.ptr(), wb.value, n, 32))
     assert not ok(lib.adlhip_radix_sort_u32(dev._h, None, tmp.ptr(), work.ptr(), wb.value, n, 32))
@@ -1551,3 +1556,61 @@ def test_hybrid_form_whole_u32_keys(dev):
     finally:
         dev.setParam("sort.msd2", 1)
         p.close()
+
+
+def test_scratch_levels_and_graceful_degradation(dev):
+    """The work buffer decides the path, never the result: with the minimum (level 0 = the reference's own contract, a digit
+    table beside the partner array, Pprims.cpp:332-337) a sort runs the per-digit three-kernel passes; with the full-speed size for
+    whole keys a partial-bit sort (whose stable form needs more) still runs, on the fastest path that fits; level 1 for those bits
+    gives it the large sort.  Sizes are monotone in n at both levels for partial bits too."""
+    import ctypes
+    lib = _lib.load()
+    n = (1 << 22) + 77
+    keys = oracle.keys_u32(n, seed=8)
+
+    def sizes(kind, nn, bits, level):
+        tb, wb = ctypes.c_size_t(), ctypes.c_size_t()
+        assert lib.adlhip_radix_sort_scratch_bytes_for(dev._h, kind, nn, bits, level, ctypes.byref(tb), ctypes.byref(wb)) == 0
+        return tb.value, wb.value
+
+    t0, w0 = sizes(0, n, 32, 0)
+    t1, w1 = sizes(0, n, 32, 1)
+    t2, w2 = sizes(0, n, 28, 1)
+    assert t0 == t1 == t2 and w0 < (2 << 20) < w1 < w2, (w0, w1, w2)
+    set_algo(dev, (-1, 8, -1))
+    dev.setParam("sort.msd2", 2)
+    data, tmp = Buffer(dev, n, np.uint32), Buffer(dev, n, np.uint32)
+    try:
+        for work_bytes, bits, want in ((w0, 32, {"count_u32_8b", "scan_table", "scatter_u32_8b"}),
+                                       (w1, 32, LARGE_U32),
+                                       (w1, 28, None),          # the stable form's slabs do not fit: any slower path will do
+                                       (w2, 28, {"msd2s_prep", "msd2s_pass1_u32", "msd2s_pass2_u32", "msd2s_offsets", "segment_sort_wave_u32"})):
+            work = Buffer(dev, work_bytes, np.uint8)
+            data.write(keys)
+            dev.toggleProfiling(True); dev.profile(reset=True)
+            check(lib.adlhip_radix_sort_u32(dev._h, data.ptr(), tmp.ptr(), work.ptr(), work_bytes, n, bits), "sort")
+            prof = dev.profile(reset=True); dev.toggleProfiling(False)
+            if want is not None:
+                assert set(prof) == want, (work_bytes, bits, prof)
+            else:
+                assert "msd2s_pass1_u32" not in prof, prof
+            assert np.array_equal(data.toHost(), oracle.sort_u32_bits(keys, bits)), (work_bytes, bits)
+            work.release()
+        # one byte less than the minimum is refused
+        work = Buffer(dev, w0, np.uint8)
+        assert lib.adlhip_radix_sort_u32(dev._h, data.ptr(), tmp.ptr(), work.ptr(), w0 - 1, n, 32) != 0
+        assert b"minimum" in lib.adlhip_last_error()
+        work.release()
+    finally:
+        dev.toggleProfiling(False)
+        dev.setParam("sort.msd2", 1)
+        data.release(); tmp.release()
+    rng = np.random.default_rng(6)
+    sz = sorted(set([1 << k for k in range(12, 29)] + [(16 << 20) - 1, 16 << 20, (96 << 20) + 1] + [int(x) for x in rng.integers(1 << 12, 3 << 27, 120)]))
+    for kind, bits in ((0, 28), (0, 16), (1, 24), (2, 44), (3, 20)):
+        for level in (0, 1):
+            last = 0
+            for nn in sz:
+                w = sizes(kind, nn, bits, level)[1]
+                assert w >= last, (kind, bits, level, nn, w, last)
+                last = w
