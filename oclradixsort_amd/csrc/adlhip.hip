@@ -679,7 +679,7 @@ template <typename E, int K, typename S = E, bool SOA = false>
 int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* seg_start, size_t num_segments, int low_bits,
                              const uint32_t* seg_cnt = nullptr, uint32_t in_stride = 0, const uint32_t* gate = nullptr,
                              const uint32_t* dyn_low_bits = nullptr, uint32_t* out_vals = nullptr, const uint32_t* list = nullptr,
-                             const uint32_t* list_cnt = nullptr)
+                             const uint32_t* list_cnt = nullptr, uint32_t seg_shift = 8)
 {
     // a wave's LDS: its tile + 256 counters; waves per workgroup so that a workgroup takes at most ~48 KiB (three per CU)
     constexpr size_t per_wave = sizeof(E) * 64 * K + 256 * 4;
@@ -696,7 +696,7 @@ int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32
             const uint32_t grid = (uint32_t)((slots + WAVES - 1) / WAVES);
             return launch(d, sizeof(E) == 4 ? "segment_sort_listed_u32" : "segment_sort_listed_e64", [&] {
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, d->stream, in, out, seg_start, (uint32_t)num_segments,
-                                   (uint32_t)low_bits, d->d_fault, seg_cnt, in_stride, gate, dyn_low_bits, out_vals, list, list_cnt);
+                                   (uint32_t)low_bits, d->d_fault, seg_cnt, in_stride, gate, dyn_low_bits, out_vals, list, list_cnt, seg_shift);
             });
         } else {
             return fail("internal: no list form for SoA");
@@ -707,14 +707,14 @@ int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32
     const uint32_t grid = (uint32_t)((num_segments + WAVES - 1) / WAVES);
     return launch(d, sizeof(E) == 4 ? "segment_sort_wave_u32" : "segment_sort_wave_e64", [&] {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, d->stream, in, out, seg_start, (uint32_t)num_segments,
-                           (uint32_t)low_bits, d->d_fault, seg_cnt, in_stride, gate, dyn_low_bits, out_vals, list, list_cnt);
+                           (uint32_t)low_bits, d->d_fault, seg_cnt, in_stride, gate, dyn_low_bits, out_vals, list, list_cnt, seg_shift);
     });
 }
 
 // the binning finish of the large keys-only sort (hybrid_kernels.hpp bin_segment_sort_kernel): one workgroup per segment slab
 template <typename E, typename S, int NT, int K, int BITS>
 int launch_bin_segment_sort(adlhip_device* d, const S* in, E* out, const uint32_t* seg_off, const uint32_t* seg_cnt, uint32_t in_stride,
-                            uint32_t* mode, uint32_t* hard_list)
+                            uint32_t* mode, uint32_t* hard_list, uint32_t seg_shift = 8)
 {
     auto kern = adlhip::bin_segment_sort_kernel<E, S, NT, K, BITS>;
     const size_t lds = align_up(sizeof(S) * NT * K, 16) + ((size_t)(1 << BITS) / 2) * 4 + (2 * NT / 64 + 4) * 4;
@@ -722,10 +722,10 @@ int launch_bin_segment_sort(adlhip_device* d, const S* in, E* out, const uint32_
     // one workgroup per segment.  (The kernel can loop -- a grid of resident workgroups that take segments in turns and request the
     // next one's keys early -- but measured slower: 256 Mi u64 keys 1.02 vs 0.89 ms, 64 Mi 0.33 vs 0.26; a workgroup that leaves
     // hands its LDS to the next one while its stores drain.)
-    const uint32_t grid = 65536u;
+    const uint32_t grid = 256u << seg_shift;
     return launch(d, sizeof(E) == 4 ? "segment_sort_bin_u32" : "segment_sort_bin_u64", [&] {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, d->stream, in, out, seg_off, seg_cnt, in_stride, 65536u, (const uint32_t*)mode,
-                           mode + adlhip::kDynHardCnt, hard_list, d->d_fault);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, d->stream, in, out, seg_off, seg_cnt, in_stride, grid, (const uint32_t*)mode,
+                           mode + adlhip::kDynHardCnt, hard_list, d->d_fault, seg_shift);
     });
 }
 
@@ -898,7 +898,7 @@ int mid_sort_keys(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, s
     pa.src_counts = nullptr; pa.n = (uint32_t)n; pa.src_stride = 0; pa.tiles_per_bucket = 1; pa.dst_stride = L.stride;
     pa.dst_total = 256u * L.stride; pa.start_bit = 24; pa.zero_me = state + 8194;
     pa.sample = nullptr; pa.which_digit = 0; pa.dst16 = 0;
-    pa.place = nullptr; pa.status_a = nullptr; pa.pieces = 0; pa.rows_per_chain_a = 0; pa.slice = 0;
+    pa.place = nullptr; pa.status_a = nullptr; pa.pieces = 0; pa.rows_per_chain_a = 0; pa.slice = 0; pa.seg_shift = 8;
     int rc = launch(d, "mid_bucket_scatter_u32", [&] {
         hipLaunchKernelGGL(ka, dim3(tiles), dim3(256), CA::LDS_BYTES, d->stream, pa);
     });
@@ -926,7 +926,7 @@ constexpr size_t kSlabInTmpMin = size_t(16) << 20;
 
 struct Msd2Layout {
     size_t off_mode, off_cnt, off_off, off_hard, off_coop, off_slab_a, off_slab_b, total;
-    uint32_t stride_a, stride_b, tier_b, tiles_per_bucket;
+    uint32_t stride_a, stride_b, tier_b, tiles_per_bucket, seg_shift, slots;
     bool slab_b_in_tmp;   // the second slab fits the caller's n-element scratch array (u32 keys from ~40 Mi keys: 16-bit elements,
                           // 1.5 x the mean per segment = 0.75 n * 4 bytes); the safety net, which needs that array as its partner,
                           // only ever runs when the slabs' contents are void
@@ -940,9 +940,9 @@ struct Msd2Layout {
 // (finish 118.0 vs 118.3 us at 64 Mi keys: five workgroups of four waves per CU instead of three of eight)
 constexpr uint32_t kMsd2Stride0 = 1536;
 // tile of the finish for n elements: 1280 / 1536 / 2560 / 5120 (what a wave -- or a workgroup of the binning finish -- holds)
-uint32_t msd2_tier_b(size_t n)
+uint32_t msd2_tier_b(size_t n, uint32_t slots = 65536)
 {
-    const size_t mean = (n + 65535) / 65536;
+    const size_t mean = (n + slots - 1) / slots;
     size_t sd = 1;
     while (sd * sd < mean) ++sd;
     const size_t need = mean + (15 * sd + 1) / 2;
@@ -951,14 +951,33 @@ uint32_t msd2_tier_b(size_t n)
 }
 // elements between two segment slabs: the mean + 50 % (or + 7.5 sd where that is more), at most the finish's tile.  (Round 2 spaced
 // the slabs by the tile whatever n was: 168 MB of second slab for 2 Mi keys.)
-uint32_t msd2_stride_b(size_t n)
+uint32_t msd2_stride_b(size_t n, uint32_t slots = 65536)
 {
-    const size_t mean = (n + 65535) / 65536;
+    const size_t mean = (n + slots - 1) / slots;
     size_t sd = 1;
     while (sd * sd < mean) ++sd;
     const size_t want = align_up(std::max(mean + mean / 2, mean + (15 * sd + 1) / 2) + 8, 64);
-    return (uint32_t)std::min<size_t>(want, msd2_tier_b(n));
+    return (uint32_t)std::min<size_t>(want, msd2_tier_b(n, slots));
 }
+
+// Width w of the second digit of the cursor form (hybrid_kernels.hpp slot_to_segment): 8 from 12 Mi elements up; below, as many
+// bits as leave segments of about a thousand elements -- 256 << w slots instead of 65536.  The finish then sorts 8 - w bits more
+// (u32 keys: more than 16, so the second slab holds whole keys), which costs less than launching 65536 waves for a few dozen
+// keys each (profiles/r3_narrow_second_digit.txt).
+// Measured (cursor form, 65536 segments | narrow): u32 keys 2.5 Mi 71 | 51 us, 4 Mi 81 | 58, 8 Mi 104 | 91, 16 Mi 140 | 138, 24 Mi
+// 177 | 199; u64 keys (binning finish on the ~1000-key segments) 1.5 Mi 117 | 47 us, 4 Mi 154 | 79, 16 Mi 289 | 221, 24 Mi 397 | 346.
+// bin_finish: the segments go to the binning finish (whole u64 keys, cursor form), which likes them a thousand keys long at any n;
+// the LSD finish pays for every extra bit with LDS passes, so there the narrow digit stops at 16 Mi elements.
+uint32_t msd2_seg_shift(size_t n, bool bin_finish)
+{
+    static const long long env = getenv("ADLHIP_SEGSHIFT_MAXN") ? atoll(getenv("ADLHIP_SEGSHIFT_MAXN")) : -1;   // A/B: 0 = never
+    const size_t max_n = env >= 0 ? (size_t)env : (bin_finish ? size_t(1) << 40 : size_t(16) << 20);
+    if (n >= max_n) return 8u;
+    uint32_t w = 2u;
+    while (w < 8u && (n >> (8u + w)) > 1024u) ++w;
+    return w;
+}
+
 
 Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
 {
@@ -967,8 +986,10 @@ Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
     // mean bucket + 50 % + 4096: the head-room of the segment slabs below (1536 for a mean of 1024), so that keys whose density
     // varies by up to ~45 % over the key range stay on this path (with + 3 % any mild skew went to the safety net)
     L.stride_a = (uint32_t)align_up(n / 256 + n / 512 + 4096, 64);
-    L.stride_b = msd2_stride_b(n);
-    L.tier_b = msd2_tier_b(n);
+    L.seg_shift = msd2_seg_shift(n, elem_bytes == 8);   // the cursor form sorts whole keys: 8-byte elements = u64 keys
+    L.slots = 256u << L.seg_shift;
+    L.stride_b = msd2_stride_b(n, L.slots);
+    L.tier_b = msd2_tier_b(n, L.slots);
     L.tiles_per_bucket = (L.stride_a + tile - 1) / tile;
     L.off_mode = 0;
     L.off_cnt = L.off_mode + 256;
@@ -977,8 +998,9 @@ Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
     L.off_coop = L.off_hard + 65536 * 4;                                     // safety net: table [256][256] + 256 totals
     L.off_slab_a = align_up(L.off_coop + (size_t)256 * 256 * 4 + 1024, 256);
     L.off_slab_b = align_up(L.off_slab_a + (size_t)256 * L.stride_a * elem_bytes, 256);
-    const size_t slab_b_bytes = (size_t)65536 * L.stride_b * (elem_bytes == 4 ? 2 : elem_bytes);   // u32 keys: 16-bit second slab
-    L.slab_b_in_tmp = elem_bytes == 4 && n >= kSlabInTmpMin && slab_b_bytes <= n * elem_bytes;
+    // u32 keys: 16-bit second slab (when the finish has 16 bits to sort: w = 8)
+    const size_t slab_b_bytes = (size_t)L.slots * L.stride_b * (elem_bytes == 4 && L.seg_shift == 8 ? 2 : elem_bytes);
+    L.slab_b_in_tmp = elem_bytes == 4 && L.seg_shift == 8 && n >= kSlabInTmpMin && slab_b_bytes <= n * elem_bytes;
     L.total = L.off_slab_b + (L.slab_b_in_tmp ? 0 : slab_b_bytes);
     return L;
 }
@@ -1032,7 +1054,7 @@ int msd2_probe(adlhip_device* d, const void* keys, size_t elem_bytes, int key_bi
 
 template <typename E, typename S, bool SOA = false>
 int launch_large_finish(adlhip_device* d, const E* slab_b, E* out, uint32_t* out_vals, uint32_t* seg_off, uint32_t* seg_cnt, uint32_t stride_b,
-                        uint32_t tier_b, uint32_t* mode, uint32_t* hard, int low_bits_max, bool bin);
+                        uint32_t tier_b, uint32_t* mode, uint32_t* hard, int low_bits_max, bool bin, uint32_t seg_shift = 8);
 bool use_bin_finish(const adlhip_device* d, size_t elem_bytes, bool key64, size_t n, bool whole_keys);
 
 template <typename E>
@@ -1073,7 +1095,7 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     pa.src_counts = nullptr; pa.n = (uint32_t)n;
     pa.src_stride = 0; pa.tiles_per_bucket = 1; pa.dst_stride = L.stride_a; pa.dst_total = 256u * L.stride_a; pa.start_bit = KEY_BITS - 8;
     pa.zero_me = nullptr; pa.sample = sample; pa.which_digit = 1; pa.dst16 = 0;
-    pa.place = nullptr; pa.status_a = nullptr; pa.pieces = 0; pa.rows_per_chain_a = 0; pa.slice = 0;
+    pa.place = nullptr; pa.status_a = nullptr; pa.pieces = 0; pa.rows_per_chain_a = 0; pa.slice = 0; pa.seg_shift = 8;
     const uint32_t tiles_a = (uint32_t)((n + CT::TILE - 1) / CT::TILE);
     rc = launch(d, k32 ? "msd2_pass1_u32" : "msd2_pass1_u64", [&] { hipLaunchKernelGGL(kern, dim3(tiles_a), dim3(512), CT::LDS_BYTES, d->stream, pa); });
     if (rc) return rc;
@@ -1081,9 +1103,10 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     pb.src = slab_a; pb.dst = slab_b; pb.cursors = cur_b; pb.cursor_shift = 0; pb.src_count_shift = 5; pb.flag = flag;
     pb.src_counts = cur_a; pb.n = (uint32_t)n;
     pb.src_stride = L.stride_a; pb.tiles_per_bucket = L.tiles_per_bucket; pb.dst_stride = L.stride_b;
-    pb.dst_total = 65536u * L.stride_b; pb.start_bit = KEY_BITS - 16; pb.zero_me = nullptr;
-    pb.sample = sample; pb.which_digit = 2;
-    pb.dst16 = sizeof(E) == 4 ? 1 : 0;   // u32 keys: the second slab holds the low 16 bits only
+    pb.dst_total = L.slots * L.stride_b; pb.start_bit = KEY_BITS - 16; pb.zero_me = nullptr;
+    pb.sample = sample; pb.which_digit = 2; pb.seg_shift = L.seg_shift;
+    const bool slab16 = sizeof(E) == 4 && L.seg_shift == 8;
+    pb.dst16 = slab16 ? 1 : 0;   // u32 keys: the second slab holds the low 16 bits only
     rc = launch(d, k32 ? "msd2_pass2_u32" : "msd2_pass2_u64", [&] {
         hipLaunchKernelGGL(kern2, dim3(256 * L.tiles_per_bucket), dim3(512), CT::LDS_BYTES, d->stream, pb);
     });
@@ -1095,25 +1118,32 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     using CC = adlhip::TileCfg<E, 8, 256, 16>;
     rc = launch(d, "msd2_offsets", [&] {
         hipLaunchKernelGGL(adlhip::msd2_offsets_kernel<E>, dim3(256), dim3(256), CC::LDS_BYTES, d->stream, cur_a, cur_b, flag, done, bar,
-                           seg_cnt, seg_off, mode, d->h_fault + 11, (uint32_t)n, sample, data, tmp, ctable, d->d_fault, KEY_BITS);
+                           seg_cnt, seg_off, mode, d->h_fault + 11, (uint32_t)n, sample, data, tmp, ctable, d->d_fault, KEY_BITS,
+                           8u - L.seg_shift);
     });
     if (rc) return rc;
     // the finish sorts the bits below the second digit (the offsets kernel has published how many)
-    using S = typename std::conditional<sizeof(E) == 4, uint16_t, E>::type;   // what pass 2 wrote
+    using S = typename std::conditional<sizeof(E) == 4, uint16_t, E>::type;   // what pass 2 wrote (w = 8)
     uint32_t* hard = reinterpret_cast<uint32_t*>(wb + L.off_hard);
-    return launch_large_finish<E, S>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, L.tier_b, mode, hard, KEY_BITS - 16,
-                                     use_bin_finish(d, sizeof(E), sizeof(E) == 8, n, true));
+    const int low_max = KEY_BITS - 8 - (int)L.seg_shift;
+    // (whole u64 keys: the binning finish wants segments of ~384 keys and more -- 24 Mi keys in 65536 segments, or any n with a
+    // narrow second digit, which leaves segments of about a thousand keys)
+    const bool bin = use_bin_finish(d, sizeof(E), sizeof(E) == 8, L.seg_shift < 8 ? (size_t(24) << 20) : n, true);
+    if (sizeof(E) == 4 && !slab16)
+        return launch_large_finish<E, E>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, L.tier_b, mode, hard, low_max, bin, L.seg_shift);
+    return launch_large_finish<E, S>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, L.tier_b, mode, hard, low_max, bin, L.seg_shift);
 }
 
 // ---- the same for {key, value} pairs, STABLE: look-back instead of cursors (hybrid_kernels.hpp msd_lookback_scatter_kernel) --
-constexpr size_t kMsd2sAutoMin = size_t(6) << 20;   // pairs; measured: 4 Mi pairs 0.133 vs 0.102 ms, 8 Mi 0.172 vs 0.183
+constexpr size_t kMsd2sAutoMin = size_t(1) << 20;   // pairs; measured with the narrow second digit: 1.5 Mi pairs 55 vs 89 us (three-kernel
+                                                    // passes), 4 Mi 89 vs 105, 8 Mi 135 vs 183 (profiles/r3_narrow_second_digit.txt)
 constexpr size_t kMsd2sMax = (size_t(1) << 28) + (size_t(1) << 22);
 // tile of the look-back passes: TileCfg<uint64_t, 8, 512, 16> = 8192 pairs, TileCfg<uint32_t, 8, 512, 32> = 16384 keys
 constexpr uint32_t msd2s_tile(size_t elem_bytes) { return elem_bytes == 8 ? 8192u : 16384u; }
 
 struct Msd2sLayout {
     size_t off_mode, off_place, off_cnt, off_off, off_hard, off_coop, off_tickets, off_status_a, off_status_b, off_slab_a, off_slab_b, total;
-    uint32_t pieces, slice, rows_a, rows_b, stride_a, stride_b, tier_b, ticket_words;
+    uint32_t pieces, slice, rows_a, rows_b, stride_a, stride_b, tier_b, ticket_words, seg_shift, slots;
     size_t status_bytes_a, status_bytes_b;
     bool slab_b_in_tmp;
 };
@@ -1147,8 +1177,11 @@ Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8, bool slab16 = false)
     L.rows_a = L.slice / kMsd2sTile;
     // the most tiles a bucket can have: pass B's tiles run across the sub-slabs, and a sub-slab holds at most its stride
     L.rows_b = (uint32_t)(((size_t)L.pieces * L.stride_a + kMsd2sTile - 1) / kMsd2sTile);
-    L.stride_b = msd2_stride_b(n);
-    L.tier_b = msd2_tier_b(n);
+    // (whole u32 keys keep 65536 segments: their second slab holds 16-bit keys only while the finish has 16 bits to sort)
+    L.seg_shift = slab16 ? 8u : msd2_seg_shift(n, false);
+    L.slots = 256u << L.seg_shift;
+    L.stride_b = msd2_stride_b(n, L.slots);
+    L.tier_b = msd2_tier_b(n, L.slots);
     L.ticket_words = (32 + 256) * adlhip::kTicketStride;
     L.status_bytes_a = (size_t)L.pieces * L.rows_a * 1024;
     L.status_bytes_b = (size_t)256 * L.rows_b * 1024;
@@ -1171,7 +1204,7 @@ Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8, bool slab16 = false)
     L.off_status_b = L.off_status_a + rows_a_bound * 1024;
     L.off_slab_a = align_up(L.off_status_b + 256 * rows_b_bound * 1024, 256);
     L.off_slab_b = align_up(L.off_slab_a + 256 * bucket_bound * elem_bytes, 256);
-    const size_t slab_b_bytes = (size_t)65536 * L.stride_b * (slab16 ? 2 : elem_bytes);
+    const size_t slab_b_bytes = (size_t)L.slots * L.stride_b * (slab16 ? 2 : elem_bytes);
     L.slab_b_in_tmp = slab16 && n >= kSlabInTmpMin && slab_b_bytes <= n * elem_bytes;
     L.total = L.off_slab_b + (L.slab_b_in_tmp ? 0 : slab_b_bytes);
     if ((size_t)L.pieces * L.rows_a > rows_a_bound || L.rows_b > rows_b_bound || (size_t)L.pieces * L.stride_a > bucket_bound)
@@ -1210,28 +1243,30 @@ LargeForm large_sort_form(const adlhip_device* d, size_t elem_bytes, bool keys, 
 // LSD finish's list form for what it handed over) or the wave-per-segment LSD finish.  S = what the second slab holds.
 template <typename E, typename S, bool SOA>
 int launch_large_finish(adlhip_device* d, const E* slab_b, E* out, uint32_t* out_vals, uint32_t* seg_off, uint32_t* seg_cnt, uint32_t stride_b,
-                        uint32_t tier_b, uint32_t* mode, uint32_t* hard, int low_bits_max, bool bin)
+                        uint32_t tier_b, uint32_t* mode, uint32_t* hard, int low_bits_max, bool bin, uint32_t seg_shift)
 {
-    // tier_b = the tile that holds a segment (msd2_tier_b); stride_b <= tier_b = the spacing of the segment slabs
+    // tier_b = the tile that holds a segment (msd2_tier_b); stride_b <= tier_b = the spacing of the segment slabs;
+    // 256 << seg_shift slots (hybrid_kernels.hpp slot_to_segment)
     const uint32_t* lowb = mode + adlhip::kDynLowBits;
+    const size_t slots = (size_t)256 << seg_shift;
     if constexpr (!SOA) {
         if (bin) {
             const S* sb = reinterpret_cast<const S*>(slab_b);
             int rc;
-            if (tier_b <= kMsd2Stride0) rc = launch_bin_segment_sort<E, S, 256, 6, 11>(d, sb, out, seg_off, seg_cnt, stride_b, mode, hard);
-            else if (tier_b == 2560) rc = launch_bin_segment_sort<E, S, 256, 10, 12>(d, sb, out, seg_off, seg_cnt, stride_b, mode, hard);
-            else rc = launch_bin_segment_sort<E, S, 512, 10, 12>(d, sb, out, seg_off, seg_cnt, stride_b, mode, hard);
+            if (tier_b <= kMsd2Stride0) rc = launch_bin_segment_sort<E, S, 256, 6, 11>(d, sb, out, seg_off, seg_cnt, stride_b, mode, hard, seg_shift);
+            else if (tier_b == 2560) rc = launch_bin_segment_sort<E, S, 256, 10, 12>(d, sb, out, seg_off, seg_cnt, stride_b, mode, hard, seg_shift);
+            else rc = launch_bin_segment_sort<E, S, 512, 10, 12>(d, sb, out, seg_off, seg_cnt, stride_b, mode, hard, seg_shift);
             if (rc) return rc;
             const uint32_t* hc = mode + adlhip::kDynHardCnt;
-            if (tier_b <= kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc);
-            if (tier_b == 2560) return launch_wave_segment_sort<E, 40, S>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc);
-            return launch_wave_segment_sort<E, 80, S>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc);
+            if (tier_b <= kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S>(d, slab_b, out, seg_off, slots, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc, seg_shift);
+            if (tier_b == 2560) return launch_wave_segment_sort<E, 40, S>(d, slab_b, out, seg_off, slots, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc, seg_shift);
+            return launch_wave_segment_sort<E, 80, S>(d, slab_b, out, seg_off, slots, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc, seg_shift);
         }
     }
-    if (tier_b == 1280) return launch_wave_segment_sort<E, 20, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
-    if (tier_b == kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
-    if (tier_b == 2560) return launch_wave_segment_sort<E, 40, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
-    return launch_wave_segment_sort<E, 80, S, SOA>(d, slab_b, out, seg_off, 65536, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals);
+    if (tier_b == 1280) return launch_wave_segment_sort<E, 20, S, SOA>(d, slab_b, out, seg_off, slots, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals, nullptr, nullptr, seg_shift);
+    if (tier_b == kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S, SOA>(d, slab_b, out, seg_off, slots, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals, nullptr, nullptr, seg_shift);
+    if (tier_b == 2560) return launch_wave_segment_sort<E, 40, S, SOA>(d, slab_b, out, seg_off, slots, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals, nullptr, nullptr, seg_shift);
+    return launch_wave_segment_sort<E, 80, S, SOA>(d, slab_b, out, seg_off, slots, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals, nullptr, nullptr, seg_shift);
 }
 
 // whole u64 keys: the binning finish pays from a mean segment of ~384 keys (16 Mi keys: 0.144 vs 0.148 ms, 4 Mi: 0.116 vs 0.098,
@@ -1303,7 +1338,7 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
     pa.flag = flag; pa.fault = d->d_fault; pa.place = place; pa.which_digit = 1; pa.n = (uint32_t)n; pa.chains = L.pieces; pa.pieces = L.pieces;
     pa.rows_per_chain = L.rows_a; pa.slice = L.slice; pa.src_stride = 0; pa.status_a = nullptr; pa.rows_per_chain_a = 0;
     pa.dst_stride = L.stride_a; pa.dst_total = 256u * L.pieces * L.stride_a;
-    pa.soa_keys = soa_keys; pa.soa_vals = soa_vals; pa.dst16 = 0;
+    pa.soa_keys = soa_keys; pa.soa_vals = soa_vals; pa.dst16 = 0; pa.seg_shift = 8;
     rc = launch(d, k32 ? "msd2s_pass1_u32" : KEY64 ? "msd2s_pass1_u64" : soa_keys ? "msd2s_pass1_soa" : "msd2s_pass1_kv32", [&] {
         hipLaunchKernelGGL(kern, dim3(L.pieces * L.rows_a), dim3(512), CT::LDS_BYTES, d->stream, pa);
     });
@@ -1319,9 +1354,10 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
             adlhip::BucketPass<E> pc;
             pc.src = slab_a; pc.dst = slab_b; pc.cursors = cur_b; pc.cursor_shift = 0; pc.src_count_shift = 0; pc.flag = flag;
             pc.src_counts = nullptr; pc.n = (uint32_t)n; pc.src_stride = L.stride_a; pc.tiles_per_bucket = L.rows_b;
-            pc.dst_stride = L.stride_b; pc.dst_total = 65536u * L.stride_b; pc.start_bit = 0; pc.zero_me = nullptr; pc.sample = nullptr;
+            pc.dst_stride = L.stride_b; pc.dst_total = L.slots * L.stride_b; pc.start_bit = 0; pc.zero_me = nullptr; pc.sample = nullptr;
             pc.which_digit = 2; pc.dst16 = slab16 ? 1 : 0;
             pc.place = place; pc.status_a = status_a; pc.pieces = L.pieces; pc.rows_per_chain_a = L.rows_a; pc.slice = L.slice;
+            pc.seg_shift = L.seg_shift;
             rc = launch(d, k32 ? "msd2h_pass2_u32" : "msd2h_pass2_u64", [&] {
                 hipLaunchKernelGGL(kern2, dim3(256 * L.rows_b), dim3(512), CT::LDS_BYTES, d->stream, pc);
             });
@@ -1332,7 +1368,7 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
     pb.src = slab_a; pb.dst = slab_b; pb.status = status_b; pb.status_bytes = (uint32_t)L.status_bytes_b;
     pb.tickets = tickets + 32 * adlhip::kTicketStride; pb.which_digit = 2; pb.chains = 256; pb.rows_per_chain = L.rows_b;
     pb.src_stride = L.stride_a; pb.status_a = status_a; pb.rows_per_chain_a = L.rows_a; pb.dst_stride = L.stride_b;
-    pb.dst_total = 65536u * L.stride_b;
+    pb.dst_total = L.slots * L.stride_b; pb.seg_shift = L.seg_shift;
     pb.soa_keys = nullptr; pb.soa_vals = nullptr;
     pb.dst16 = slab16 ? 1 : 0;
     if (!cur_b) {
@@ -1347,19 +1383,19 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
         hipLaunchKernelGGL((adlhip::msd2s_offsets_kernel<E, CT::TILE>), dim3(256), dim3(256), CC::LDS_BYTES, d->stream,
                            (const uint32_t*)status_a, L.rows_a, L.slice, L.pieces, (const uint32_t*)status_b, L.rows_b, L.stride_a, flag,
                            done, bar, seg_cnt, seg_off, mode, d->h_fault + 11, (uint32_t)n, (const adlhip::StablePlace*)place,
-                           soa_keys ? slab_a : data, soa_keys ? slab_b : tmp, ctable, d->d_fault, soa_keys, soa_vals, cur_b);
+                           soa_keys ? slab_a : data, soa_keys ? slab_b : tmp, ctable, d->d_fault, soa_keys, soa_vals, cur_b, 8u - L.seg_shift);
     });
     if (rc) return rc;
-    const int low_max = sort_bits - 16;
-    const bool bin = use_bin_finish(d, sizeof(E), KEY64, n, whole);
+    const int low_max = sort_bits - 8 - (int)L.seg_shift;
+    const bool bin = use_bin_finish(d, sizeof(E), KEY64, L.seg_shift < 8 ? (size_t(24) << 20) : n, whole);
     if constexpr (k32) {
-        if (slab16) return launch_large_finish<E, uint16_t>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, L.tier_b, mode, hard, low_max, bin);
-        return launch_large_finish<E, E>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, L.tier_b, mode, hard, low_max, false);
+        if (slab16) return launch_large_finish<E, uint16_t>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, L.tier_b, mode, hard, low_max, bin, L.seg_shift);
+        return launch_large_finish<E, E>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, L.tier_b, mode, hard, low_max, false, L.seg_shift);
     } else {
         if (soa_keys)   // the finish writes keys and values to their own arrays
             return launch_large_finish<E, E, true>(d, slab_b, reinterpret_cast<E*>(soa_keys), soa_vals, seg_off, seg_cnt, L.stride_b, L.tier_b, mode,
-                                                   hard, low_max, false);
-        return launch_large_finish<E, E>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, L.tier_b, mode, hard, low_max, bin);
+                                                   hard, low_max, false, L.seg_shift);
+        return launch_large_finish<E, E>(d, slab_b, data, nullptr, seg_off, seg_cnt, L.stride_b, L.tier_b, mode, hard, low_max, bin, L.seg_shift);
     }
 }
 

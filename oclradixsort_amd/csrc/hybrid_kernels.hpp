@@ -514,6 +514,18 @@ __device__ __forceinline__ void wave_sort_dispatch(int rows, const S* __restrict
     }
 }
 
+// Narrow second digit (small inputs): with fewer than ~48 Mi elements 65536 segments are too many -- the finish then spends its
+// time launching waves that hold a few dozen keys each (4 Mi keys: 44 us for the finish alone) -- so the second MSD digit is
+// read `8 - w` bits higher: the field [top - 8 - w, top - w) overlaps the first digit in its upper 8 - w bits, which are the same
+// for every key of a bucket, so only 2^w of its 256 values occur per bucket, cursors, counts and offsets stay indexed
+// [bucket][8-bit digit] as ever, and the finish sorts the top - 8 - w bits below.  Only the slabs and the finish's grid are
+// compact: slot c = (bucket << w) | (digit & (2^w - 1)), 256 << w slots in all.  w = 8: slot = segment.
+__device__ __forceinline__ uint32_t slot_to_segment(uint32_t slot, uint32_t w)
+{
+    const uint32_t b = slot >> w;
+    return (b << 8) | ((b & ((1u << (8u - w)) - 1u)) << w) | (slot & ((1u << w) - 1u));
+}
+
 // LIST: the segments to do are list[0 .. *list_cnt) -- what bin_segment_sort_kernel handed over, usually nothing -- taken in turns
 // by a small grid; otherwise wave i of the grid does segment i.  (One call site of the body per instantiation: with two, the
 // compiler stops inlining the 80-row bodies and the kernel runs three times slower.)
@@ -525,7 +537,7 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
                                                                         const uint32_t* __restrict__ dyn_low_bits,
                                                                         uint32_t* out_vals /* SOA: out = the key array */,
                                                                         const uint32_t* __restrict__ list,
-                                                                        const uint32_t* __restrict__ list_cnt)
+                                                                        const uint32_t* __restrict__ list_cnt, uint32_t seg_shift)
 {
     if (gate && *gate != 0u) return;
     if (dyn_low_bits) low_bits = *dyn_low_bits;
@@ -544,8 +556,9 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
         limit = nl < num_segments ? nl : num_segments;
     }
     for (; slot < limit; slot = LIST ? slot + gridDim.x * (uint32_t)WAVES : limit) {
-        uint32_t seg = slot;
-        if constexpr (LIST) seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[slot]);
+        uint32_t sl = slot;   // slab number (slab forms); num_segments counts slots
+        if constexpr (LIST) sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[slot]);
+        const uint32_t seg = seg_shift < 8u ? slot_to_segment(sl, seg_shift) : sl;
         const uint32_t begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_start[seg]);
         const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seg_cnt ? seg_cnt[seg] : seg_start[seg + 1] - begin));
         if (m == 0u) continue;
@@ -554,17 +567,17 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
             continue;
         }
         if constexpr (SOA) {
-            const E* src = in + (size_t)seg * in_stride;
+            const E* src = in + (size_t)sl * in_stride;
             wave_sort_dispatch<E, RMIN, K, STEP, true, E, true>((int)((m + 63u) >> 6), src,
                                                                 reinterpret_cast<E*>(reinterpret_cast<uint32_t*>(out) + begin),
                                                                 out_vals + begin, m, lane, buf, cnt, low_bits, E(0));
         } else if constexpr (sizeof(S) == sizeof(E)) {
-            const E* src = in + (seg_cnt ? (size_t)seg * in_stride : (size_t)begin);
+            const E* src = in + (seg_cnt ? (size_t)sl * in_stride : (size_t)begin);
             wave_sort_dispatch<E, RMIN, K, STEP, true, E, false>((int)((m + 63u) >> 6), src, out + begin, nullptr, m, lane, buf, cnt,
                                                                  low_bits, E(0));
         } else {
-            // slab form with 16-bit elements: the key's bits above low_bits are (sampled prefix, segment number)
-            const S* src = reinterpret_cast<const S*>(in) + (size_t)seg * in_stride;
+            // slab form with 16-bit elements: the key's bits above low_bits are (sampled prefix, segment number); seg_shift = 8
+            const S* src = reinterpret_cast<const S*>(in) + (size_t)sl * in_stride;
             const E hi = (E)(((dyn_low_bits[1] << 16) | seg) << low_bits);
             wave_sort_dispatch<E, RMIN, K, STEP, true, S, false>((int)((m + 63u) >> 6), src, out + begin, nullptr, m, lane, buf, cnt,
                                                                  low_bits, hi);
@@ -602,7 +615,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void bin_segment_sort_kern
                                                               const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_cnt,
                                                               uint32_t in_stride, uint32_t num_segments, const uint32_t* __restrict__ mode,
                                                               uint32_t* __restrict__ hard_cnt, uint32_t* __restrict__ hard_list,
-                                                              uint32_t* fault)
+                                                              uint32_t* fault, uint32_t seg_shift)
 {
     if (mode[kDynMode] != 0u) return;   // the safety net has sorted instead
     constexpr int CAP = NT * K;
@@ -629,9 +642,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void bin_segment_sort_kern
     if constexpr (sizeof(S) != sizeof(E)) prefix = mode[kDynLowBits + 1] << 16;
 
     // persistent: workgroup g takes segments g, g + G, ...; the keys of the next one are requested while this one is sorted
-    uint32_t seg = blockIdx.x;
+    uint32_t seg = blockIdx.x;   // slot = slab number; sg(slot) = segment number (slot_to_segment)
     if (seg >= num_segments) return;
-    uint32_t m = seg_cnt[seg];
+    auto sg = [&](uint32_t slot) -> uint32_t { return seg_shift < 8u ? slot_to_segment(slot, seg_shift) : slot; };
+    uint32_t m = seg_cnt[sg(seg)];
     S e[K];
     {
         const S* __restrict__ src = in + (size_t)seg * in_stride;
@@ -646,10 +660,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void bin_segment_sort_kern
         asm volatile("" : "+v"(tid));
         const uint32_t next = seg + gridDim.x;
         const bool more = next < num_segments;
-        const uint32_t m_next = more ? seg_cnt[next] : 0u;
+        const uint32_t m_next = more ? seg_cnt[sg(next)] : 0u;
         E hi_bits = E(0);
-        if constexpr (sizeof(S) != sizeof(E)) hi_bits = (E)((prefix | seg) << low_bits);
-        E* __restrict__ dst = out + seg_off[seg];
+        if constexpr (sizeof(S) != sizeof(E)) hi_bits = (E)((prefix | seg) << low_bits);   // 16-bit slabs: seg_shift = 8
+        E* __restrict__ dst = out + seg_off[sg(seg)];
         auto prefetch_next = [&]() {
             if (more) {
                 const S* __restrict__ src = in + (size_t)next * in_stride;
@@ -816,6 +830,7 @@ struct BucketPass {
     const StablePlace* place;
     const uint32_t* status_a;
     uint32_t pieces, rows_per_chain_a, slice;
+    uint32_t seg_shift;           // second pass: width w of the second digit (see slot_to_segment); 8 otherwise
 };
 
 // Digit placement of the large keys-only sort, chosen on the device from a sample of the keys: keys that do not use their top
@@ -1031,6 +1046,7 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
         start_bit = place.top - 8 * a.which_digit;
     }
     if constexpr (PASS == 3) start_bit = (int)a.place->top - 16;
+    if constexpr (PASS >= 2) start_bit += 8 - (int)a.seg_shift;   // narrow second digit: the field sits 8 - w bits higher
     uint32_t* my_wcnt = s_wcnt + w * BINS;
     const IO io{a.src, a.dst};
     const bool scaled = dst_fits32<IO>(a.dst_total);
@@ -1155,7 +1171,9 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
         const bool over = (at4.x + real4.x > a.dst_stride) | (at4.y + real4.y > a.dst_stride) | (at4.z + real4.z > a.dst_stride) |
                           (at4.w + real4.w > a.dst_stride);
         if (over) __hip_atomic_fetch_or(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t d0 = cursor_base + 4u * (uint32_t)lane;
+        uint32_t d0 = cursor_base + 4u * (uint32_t)lane;
+        if constexpr (PASS >= 2)   // slab of (bucket, digit): slot (bucket << w) | (digit & (2^w - 1)); w = 8: the same number
+            d0 = ((cursor_base >> 8) << a.seg_shift) + ((4u * (uint32_t)lane) & ((1u << a.seg_shift) - 1u));
         u32x4 go;   // destination index = goff[digit] + tile position
         go.x = (d0 + 0u) * a.dst_stride + at4.x - toff4.x;
         go.y = (d0 + 1u) * a.dst_stride + at4.y - toff4.y;
@@ -1200,7 +1218,7 @@ __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, 
                                                            uint32_t* bar, uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_off,
                                                            uint32_t* __restrict__ mode, uint32_t* host_mode, uint32_t n,
                                                            uint32_t* sample, E* data, E* tmp, uint32_t* __restrict__ ctable,
-                                                           uint32_t* fault, int key_bits)
+                                                           uint32_t* fault, int key_bits, uint32_t d2_shift /* 8 - w, slot_to_segment */)
 {
     __shared__ uint32_t s_wsum[256 / 64 + 1];
     __shared__ uint32_t s_misc[4];
@@ -1228,7 +1246,7 @@ __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, 
             mode[kDynHardCnt] = 0u;
             seg_off[65536] = n;
             if (sample) {   // the finish sorts the bits below the second digit; the sample words go back to or = 0 / and = ~0
-                mode[kDynLowBits] = (uint32_t)(msd2_placement(sample).top - 16);
+                mode[kDynLowBits] = (uint32_t)(msd2_placement(sample).top - 16) + d2_shift;
                 mode[kDynLowBits + 1] = (uint32_t)msd2_placement(sample).prefix;   // for the finish of a 16-bit second slab
                 __hip_atomic_store(sample + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(sample + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1331,6 +1349,7 @@ struct LookbackPass {
     const uint32_t* soa_vals;
     int dst16;                    // pass B of u32 keys: the destination slabs hold uint16_t -- a segment's keys share everything above
                                   // their low 16 bits (BucketPass::dst16)
+    uint32_t seg_shift;           // pass B: width w of the second digit (slot_to_segment); 8 otherwise
 };
 
 template <typename E, int NT, int K, bool KEY64>
@@ -1353,7 +1372,8 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
     // (chain = i % 256, which spreads every moment's writes over all 65536 slabs, measured 0.299 vs 0.272 ms at 64 Mi pairs and
     // 0.637 vs 0.527 ms at 128 Mi)
     const uint32_t chain = a.which_digit == 2 ? blockIdx.x / a.rows_per_chain : blockIdx.x % a.chains;
-    const int start_bit = (int)a.place->top - 8 * a.which_digit;
+    // (pass B with a narrow second digit: the field sits 8 - w bits higher, see slot_to_segment)
+    const int start_bit = (int)a.place->top - 8 * a.which_digit + (a.which_digit == 2 ? 8 - (int)a.seg_shift : 0);
 
     // ---- ticket -> tile index in the chain -> where the tile's elements are ------------------------------------------------
     if (w == 0) {
@@ -1561,8 +1581,8 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
         if (a.which_digit == 1) {
             sl.x = (d0 + 0u) * a.pieces + chain; sl.y = (d0 + 1u) * a.pieces + chain; sl.z = (d0 + 2u) * a.pieces + chain;
             sl.w = (d0 + 3u) * a.pieces + chain;
-        } else {
-            sl.x = chain * 256u + d0; sl.y = sl.x + 1u; sl.z = sl.x + 2u; sl.w = sl.x + 3u;
+        } else {   // slot (bucket << w) | (digit & (2^w - 1)); w = 8: bucket * 256 + digit
+            sl.x = (chain << a.seg_shift) + (d0 & ((1u << a.seg_shift) - 1u)); sl.y = sl.x + 1u; sl.z = sl.x + 2u; sl.w = sl.x + 3u;
         }
         // an overflowing run would be written beyond its slab: park it at the slab's start instead (the result is discarded)
         u32x4 in4 = excl;
@@ -1604,7 +1624,8 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
                                                             uint32_t* __restrict__ mode, uint32_t* host_mode, uint32_t n,
                                                             const StablePlace* __restrict__ place, E* data, E* tmp,
                                                             uint32_t* __restrict__ ctable, uint32_t* fault, uint32_t* soa_keys,
-                                                            uint32_t* soa_vals, uint32_t* cursors_b /* hybrid form, else nullptr */)
+                                                            uint32_t* soa_vals, uint32_t* cursors_b /* hybrid form, else nullptr */,
+                                                            uint32_t d2_shift /* 8 - w (slot_to_segment); stable second pass: 0 */)
 {
     __shared__ uint32_t s_wsum[256 / 64 + 1];
     __shared__ uint32_t s_misc[4];
@@ -1646,7 +1667,7 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
     __syncthreads();
     if (s_misc[2] == gridDim.x - 1u && t == 0) {
         *mode = overflow ? 1u : 0u;
-        mode[kDynLowBits] = place->low_bits;
+        mode[kDynLowBits] = place->low_bits + d2_shift;
         mode[kDynLowBits + 1] = (uint32_t)place->prefix;   // for the finish of a 16-bit second slab
         mode[kDynHardCnt] = 0u;
         seg_off[65536] = n;

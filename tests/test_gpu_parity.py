@@ -1463,8 +1463,12 @@ def test_u64_keys_stable_passes_binning_finish_and_its_handover(dev):
         for n2 in ((1 << 20) + 77, 3000001, (1 << 25) + 4321, (1 << 27) + 99):   # all three tile tiers of the finish
             k = oracle.keys_u64(n2, seed=n2 & 0xff)
             assert np.array_equal(gpu_sort_u64(dev, p, k), oracle.sort_u64(k)), n2
-        dev.setParam("sort.binfinish", 1)   # the default: binning from 24 Mi keys, the LSD finish below
-        k = oracle.keys_u64(n, seed=6)
+        dev.setParam("sort.binfinish", 1)   # the default: binning where segments hold ~384 keys and more -- from 24 Mi keys in 65536
+        k = oracle.keys_u64(n, seed=6)      # segments, and below 16 Mi keys, where the second digit is narrow (8 Mi: 8192 segments)
+        got, prof = _profiled(dev, lambda: gpu_sort_u64(dev, p, k))
+        assert set(prof) == LARGE_U64_BIN, prof
+        assert np.array_equal(got, oracle.sort_u64(k))
+        k = oracle.keys_u64((5 << 22) + 9, seed=6)   # 20 Mi keys in 65536 segments of ~320: the LSD finish
         got, prof = _profiled(dev, lambda: gpu_sort_u64(dev, p, k))
         assert set(prof) == LARGE_U64_LSD, prof
         assert np.array_equal(got, oracle.sort_u64(k))
@@ -1482,9 +1486,9 @@ def test_u64_keys_stable_passes_binning_finish_and_its_handover(dev):
         assert {"msd2s_pass1_u64", "msd2h_pass2_u64", "segment_sort_bin_u64"} <= set(prof), prof
         assert np.array_equal(got, oracle.sort_u64(k))
         dev.setParam("sort.msd2", 2)
-        k = oracle.keys_u64((1 << 24) + 3, seed=8)   # ... 16 Mi + 3 keys -> cursor passes, LSD finish
+        k = oracle.keys_u64((1 << 24) + 3, seed=8)   # ... 16 Mi + 3 keys -> cursor passes, narrow second digit, binning finish
         got, prof = _profiled(dev, lambda: gpu_sort_u64(dev, p, k))
-        assert set(prof) == {"msd2_sample", "msd2_pass1_u64", "msd2_pass2_u64", "msd2_offsets", "segment_sort_wave_e64"}, prof
+        assert set(prof) == {"msd2_sample", "msd2_pass1_u64", "msd2_pass2_u64", "msd2_offsets", "segment_sort_bin_u64", "segment_sort_listed_e64"}, prof
         assert np.array_equal(got, oracle.sort_u64(k))
         k = oracle.keys_u64((1 << 25) + 3, seed=7)
         dev.setParam("sort.msd2", 4)        # cursor passes
@@ -1565,7 +1569,7 @@ def test_scratch_levels_and_graceful_degradation(dev):
     gives it the large sort.  Sizes are monotone in n at both levels for partial bits too."""
     import ctypes
     lib = _lib.load()
-    n = (1 << 22) + 77
+    n = (5 << 22) + 77   # 20 Mi keys: whole keys keep their 16-bit second slab in the partner array, a 28-bit sort cannot
     keys = oracle.keys_u32(n, seed=8)
 
     def sizes(kind, nn, bits, level):
@@ -1576,7 +1580,7 @@ def test_scratch_levels_and_graceful_degradation(dev):
     t0, w0 = sizes(0, n, 32, 0)
     t1, w1 = sizes(0, n, 32, 1)
     t2, w2 = sizes(0, n, 28, 1)
-    assert t0 == t1 == t2 and w0 < (2 << 20) < w1 < w2, (w0, w1, w2)
+    assert t0 == t1 == t2 and w0 < (4 << 20) < w1 < w2, (w0, w1, w2)
     set_algo(dev, (-1, 8, -1))
     dev.setParam("sort.msd2", 2)
     data, tmp = Buffer(dev, n, np.uint32), Buffer(dev, n, np.uint32)
@@ -1614,3 +1618,38 @@ def test_scratch_levels_and_graceful_degradation(dev):
                 w = sizes(kind, nn, bits, level)[1]
                 assert w >= last, (kind, bits, level, nn, w, last)
                 last = w
+
+
+def test_narrow_second_digit_on_small_inputs(dev):
+    """Below 16 Mi elements (u64 keys on the cursor form: at every size) the second MSD digit is narrower than 8 bits, so that
+    segments hold about a thousand elements instead of a few dozen (hybrid_kernels.hpp slot_to_segment): 256 << w slabs and
+    finish waves, the finish sorts 8 - w bits more.  Every width w = 2 ... 7 for u32 keys (whole-key second slab), u64 keys
+    (binning finish) and pairs (stable form), with keys that leave top bits unused, duplicates and skew (safety net)."""
+    p = Pprims()
+    try:
+        for forced in (4, 3):   # cursor form / stable form
+            dev.setParam("sort.msd2", forced)
+            for n in ((1 << 20) + 5, 1500000, 2500000, (1 << 22) + 77, 6000001, (1 << 23) + 1, 12000000, (1 << 24) - 3):
+                k = oracle.keys_u32(n, seed=n & 0xff)
+                assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), ("u32", forced, n)
+                k64 = oracle.keys_u64(n, seed=n & 0xff)
+                assert np.array_equal(gpu_sort_u64(dev, p, k64), oracle.sort_u64(k64)), ("u64", forced, n)
+            n = 3000001
+            u = oracle.keys_u32(n, seed=77)
+            for nm, k in {"below 2^24": u >> np.uint32(8), "below 2^19": u >> np.uint32(13), "below 2^16": u >> np.uint32(16),
+                          "one eighth of the range": (u >> np.uint32(3)) | np.uint32(0x40000000),
+                          "4096 distinct keys": (u >> np.uint32(20)) * np.uint32(0x00100801),
+                          "one heavy top byte (safety net)": np.where(np.arange(n) % 10 != 0, u >> np.uint32(8), u).astype(np.uint32),
+                          "sorted": np.sort(u)}.items():
+                assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), (nm, forced)
+        dev.setParam("sort.msd2", 2)
+        for n in ((1 << 20) + 5, 1500000, (1 << 22) + 77, 6000001, 12000000):
+            pr = oracle.pairs_kv32(n, seed=n & 0xff) & np.uint64(0xffffffff000fffff)   # 20-bit keys: duplicates, stability
+            got, prof = _profiled(dev, lambda: gpu_sort_kv(dev, p, pr))
+            assert set(prof) == LARGE_PAIRS, (n, prof)
+            assert np.array_equal(got, oracle.sort_kv32(pr)), ("pairs", n)
+            assert np.array_equal(gpu_sort_kv(dev, p, pr, 20), oracle.sort_e64_bits(pr, 20)), ("pairs, 20 bits", n)
+        DeviceUtils.waitForCompletion(dev)
+    finally:
+        dev.setParam("sort.msd2", 1)
+        p.close()
