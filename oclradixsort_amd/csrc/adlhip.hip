@@ -93,6 +93,7 @@ struct adlhip_device {
     int msd2_path = 1;        // "sort.msd2": the large sort (msd2_sort for keys, msd2s_sort for pairs); 2 = forced (tests)
     int msd2_skip = 0, msd2_backoff = 32;   // sorts the next overflow report keeps off the large sort (x8 each time, reset by a success)
     bool msd2_trusted = false;              // a good report has come in since the last bad one (msd2_decide)
+    bool msd2_waited = false;               // the handle's first probe has been waited for (msd2_first_verdict)
     uint32_t* d_msd2 = nullptr;   // the large sort's handle-owned words, allocated on first use and zero between sorts: cursors of
                                   // pass 1 (256, one 128-byte line each) and pass 2 (65536), overflow flag, done counter, the safety
                                   // net's barrier counter, the four sample words
@@ -985,7 +986,8 @@ Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
     const uint32_t tile = elem_bytes == 4 ? 16384u : 8192u;   // TileCfg<E, 8, 512, 32 | 16>
     // mean bucket + 50 % + 4096: the head-room of the segment slabs below (1536 for a mean of 1024), so that keys whose density
     // varies by up to ~45 % over the key range stay on this path (with + 3 % any mild skew went to the safety net)
-    L.stride_a = (uint32_t)align_up(n / 256 + n / 512 + 4096, 64);
+    static const int headroom_pct = getenv("ADLHIP_SLAB_A_HEADROOM_PCT") ? atoi(getenv("ADLHIP_SLAB_A_HEADROOM_PCT")) : 50;   // A/B only
+    L.stride_a = (uint32_t)align_up(n / 256 + (n / 256) * (size_t)headroom_pct / 100 + 4096, 64);
     L.seg_shift = msd2_seg_shift(n, elem_bytes == 8);   // the cursor form sorts whole keys: 8-byte elements = u64 keys
     L.slots = 256u << L.seg_shift;
     L.stride_b = msd2_stride_b(n, L.slots);
@@ -1039,6 +1041,18 @@ Msd2Choice msd2_decide(adlhip_device* d)
     return d->msd2_trusted ? kMsd2Use : kMsd2Probe;
 }
 
+// A handle's FIRST eligible sort waits for the probe's verdict (one stream synchronisation per handle: its first large sort
+// allocates the handle-owned words anyway) and takes the large sort at once when the keys fit -- round 2 sent every first sort
+// down the per-digit passes and let the verdict arrive later (0.78-0.86 ms for the first 64 Mi keys, whatever they were).  Later
+// probes (after a back-off) ride along unsynchronised as before.
+Msd2Choice msd2_first_verdict(adlhip_device* d)
+{
+    if (d->msd2_waited) return kMsd2Probe;   // not the first time: the verdict arrives with a later call
+    d->msd2_waited = true;
+    if (hipStreamSynchronize(d->stream) != hipSuccess) return kMsd2Probe;
+    return msd2_decide(d) == kMsd2Use ? kMsd2Use : kMsd2Skip;
+}
+
 // elem_bytes / key_bits of the array the keys are read from (AoS pairs: 8 / 32, the key is the low dword)
 int msd2_probe(adlhip_device* d, const void* keys, size_t elem_bytes, int key_bits, size_t n)
 {
@@ -1084,7 +1098,9 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     auto kern = adlhip::msd_bucket_scatter_kernel<E, 512, K, 1>;
     auto kern2 = adlhip::msd_bucket_scatter_kernel<E, 512, K, 2>;
     if (ensure_lds(kern, CT::LDS_BYTES) || ensure_lds(kern2, CT::LDS_BYTES)) return ADLHIP_FAILURE;
-    // where the two digits sit is chosen on the device from a sample of the keys (hybrid_kernels.hpp msd2_sample_kernel)
+    // where the two digits sit is chosen on the device from a sample of the keys (hybrid_kernels.hpp msd2_sample_kernel).  (Folding
+    // the sample into pass 1 -- every workgroup ORs and ANDs the same 1024 keys -- saves this launch and costs more than it saves:
+    // 1024 strided keys are 1024 cache lines, twice a tile's own; pass 1 at 64 Mi keys 0.150 -> 0.166 ms, nothing gained at 4 Mi.)
     int rc = launch(d, "msd2_sample", [&] {
         hipLaunchKernelGGL(adlhip::msd2_sample_kernel<E>, dim3(adlhip::kSampleWGs), dim3(64), 0, d->stream, (const E*)data, (uint32_t)n,
                            sample, flag + 2, d->d_fault);
@@ -1515,7 +1531,11 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
                        large_work_bytes(kLargeCursor, sizeof(E), n, true) <= work_bytes ? kLargeCursor : kLargeNone;
     }
     if (form != kLargeNone) {
-        const Msd2Choice c = msd2_decide(d);
+        Msd2Choice c = msd2_decide(d);
+        if (c == kMsd2Probe) {
+            if (msd2_probe(d, data, sizeof(E), sort_bits, n)) return ADLHIP_FAILURE;
+            c = msd2_first_verdict(d);
+        }
         if (c == kMsd2Use) {
             if (form == kLargeCursor) return msd2_sort<E>(d, data, tmp, work, n);
             const bool hybrid = form == kLargeHybrid;
@@ -1526,7 +1546,6 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
                 return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits);
             }
         }
-        if (c == kMsd2Probe && msd2_probe(d, data, sizeof(E), sort_bits, n)) return ADLHIP_FAILURE;
     }
     return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, work_bytes, n, plan);
 }
@@ -1690,6 +1709,18 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         if (own && d->stream) hipStreamDestroy(d->stream);
         delete d;
         return fail("cannot allocate the mid-size sort's histogram area");
+    }
+    // the large sort's handle-owned words (cursors, flags: 270 KB), zero between sorts -- allocated here rather than by a handle's
+    // first large sort, which then only has its probe to wait for
+    if (hipMalloc(&d->d_msd2, (8192 + 65536 + 64) * 4) != hipSuccess ||
+        hipMemsetAsync(d->d_msd2, 0, (8192 + 65536 + 64) * 4, d->stream) != hipSuccess) {
+        if (d->d_msd2) hipFree(d->d_msd2);
+        hipFree(d->d_mid_hist);
+        hipFree(d->d_fault);
+        hipHostFree(d->h_fault);
+        if (own && d->stream) hipStreamDestroy(d->stream);
+        delete d;
+        return fail("cannot allocate the large sort's cursors");
     }
     {   // self-test: are returning DS atomics lane-ordered on this device?  (enables "sort.rank" = 1)
         uint32_t mism = 1;
@@ -2031,9 +2062,12 @@ int adlhip_radix_sort_soa32(adlhip_device* d, uint32_t* keys, uint32_t* vals, ui
     if ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(tmp_vals)) & 15u)
         return fail("sort buffers must be 16-byte aligned");
     if (large_sort_form(d, 8, false, n, sort_bits, 32) != kLargeNone && large_work_bytes(kLargeStable, 8, n, sort_bits == 32) <= work_bytes) {
-        const Msd2Choice c = msd2_decide(d);
+        Msd2Choice c = msd2_decide(d);
+        if (c == kMsd2Probe) {
+            if (msd2_probe(d, keys, 4, sort_bits, n)) return ADLHIP_FAILURE;
+            c = msd2_first_verdict(d);
+        }
         if (c == kMsd2Use) return msd2s_sort<uint64_t, false>(d, nullptr, nullptr, work, n, sort_bits, keys, vals);
-        if (c == kMsd2Probe && msd2_probe(d, keys, 4, sort_bits, n)) return ADLHIP_FAILURE;
     }
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
     return run_sort<SoaBuf>(d, SoaBuf{keys, vals}, SoaBuf{tmp_keys, tmp_vals}, work, work_bytes, n, plan);

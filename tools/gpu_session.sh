@@ -13,7 +13,7 @@ echo "== sweep soa"; timeout -k 10 600 python tools/sweep.py --steps 10 --verify
 echo "== sweep u64 256Mi"; timeout -k 10 600 python tools/sweep.py --steps 3 --kind u64 --n 268435456 --configs=-1:8:-1:1,0:8:-1:1,1:8:-1:1 2>&1 | tee $OUT/sweep_u64.txt
 echo "== distributions"; timeout -k 10 600 python tools/distributions.py 2>&1 | tee $OUT/distributions.txt
 echo "== n curve"; timeout -k 10 900 python tools/ncurve.py 2>&1 | tee $OUT/ncurve.txt
-echo "== large-sort size curves"; timeout -k 10 300 python tools/msd2curve.py 2500000 3145728 4194304 6291456 8388608 12582912 16777216 25165824 33554432 50331648 67108864 134217728 268435456 2>&1 | tee $OUT/msd2_size_curve.txt
+echo "== large-sort size curves"; timeout -k 10 300 python tools/msd2curve.py 1500000 2500000 3145728 4194304 6291456 8388608 12582912 16777216 25165824 33554432 50331648 67108864 134217728 268435456 2>&1 | tee $OUT/msd2_size_curve.txt
 for k in kv u64; do for n in 4194304 8388608 16777216 33554432 67108864 134217728; do timeout -k 10 200 python tools/sweep.py --steps 5 --kind $k --n $n --configs=-1:8:-1:1,0:8:-1:1 2>&1 | tail -2 | sed "s/^/$k n=$n  /"; done; done | tee $OUT/large_sort_kv_u64_curve.txt
 echo "== large sort, keys of one eighth of the range (a rank of an 8-GPU sort)"; MSD2CURVE_SHIFT=3 MSD2CURVE_MODES=1,0 timeout -k 10 300 python tools/msd2curve.py 16777216 67108864 134217728 2>&1 | tee $OUT/msd2_rank_range.txt
 echo "== multi-rank rehearsal on one GPU (code path only, host-staged collectives)"
