@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,7 @@
 #include "radix_kernels.hpp"
 #include "onesweep_kernels.hpp"
 #include "hybrid_kernels.hpp"
+#include "dict_kernels.hpp"
 
 namespace {
 
@@ -94,6 +96,10 @@ struct adlhip_device {
     int msd2_skip = 0, msd2_backoff = 32;   // sorts the next overflow report keeps off the large sort (x8 each time, reset by a success)
     bool msd2_trusted = false;              // a good report has come in since the last bad one (msd2_decide)
     bool msd2_waited = false;               // the handle's first probe has been waited for (msd2_first_verdict)
+    bool msd2_probe_pending = false;        // a sort did not fit: the next eligible sort lets the probe look at the keys again
+    bool dict_hint = false;                 // the last report said "few distinct values": whole-key sorts of keys go to the counting sort
+    int dict_path = 1;                      // "sort.dict": counting sort for keys that take at most 256 values (dict_kernels.hpp); 0 = off
+    adlhip::DictBlock* d_dict = nullptr;    // its dictionary and counters (handle-owned, counters zero between sorts)
     uint32_t* d_msd2 = nullptr;   // the large sort's handle-owned words, allocated on first use and zero between sorts: cursors of
                                   // pass 1 (256, one 128-byte line each) and pass 2 (65536), overflow flag, done counter, the safety
                                   // net's barrier counter, the four sample words
@@ -1016,27 +1022,37 @@ Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
 //   * after a bad one (from the probe or from a sort that went through its safety net) the next 32 (256, 2048, 4096)
 //     eligible sorts go straight to the per-digit passes, then the probe looks again.
 // Only speed depends on any of it ("sort.msd2" = 2 forces the path, 0 = off).
-enum Msd2Choice { kMsd2Skip = 0, kMsd2Use = 1, kMsd2Probe = 2 };
+enum Msd2Choice { kMsd2Skip = 0, kMsd2Use = 1, kMsd2Probe = 2, kMsd2Dict = 3 };
 Msd2Choice msd2_decide(adlhip_device* d)
 {
     if (d->msd2_path >= 2) return kMsd2Use;
-    if (d->msd2_skip > 0) {
-        --d->msd2_skip;
-        return kMsd2Skip;
-    }
     const uint32_t report = d->h_fault[11];
     d->h_fault[11] = 0u;
-    if (report == 2u) {
+    if (report == 4u) {          // few distinct values (the probe, or a counting sort that went through)
+        d->dict_hint = true;
+        d->msd2_skip = 0;
+    } else if (report == 2u) {   // the keys did not fit (probe, large sort or counting sort)
         d->msd2_trusted = false;
+        d->dict_hint = false;
         d->msd2_skip = d->msd2_backoff;
         d->msd2_backoff = std::min(d->msd2_backoff * 8, 4096);
-        return kMsd2Skip;
-    }
-    if (report == 1u) {   // a large sort went through
+        d->msd2_probe_pending = true;   // the next sort takes the per-digit passes and lets the probe say what the keys are like now
+    } else if (report == 1u) {   // a large sort went through
         d->msd2_trusted = true;
+        d->dict_hint = false;
         d->msd2_backoff = 32;
     } else if (report == 3u) {   // the probe saw no obstacle: try the sort, but keep the back-off where it is -- keys that pass the
         d->msd2_trusted = true;  // probe and still overflow (skew at the scale of single segments) must not cycle for ever
+        d->dict_hint = false;
+    }
+    if (d->dict_hint) return kMsd2Dict;
+    if (d->msd2_skip > 0) {
+        --d->msd2_skip;
+        if (d->msd2_probe_pending) {
+            d->msd2_probe_pending = false;
+            return kMsd2Probe;
+        }
+        return kMsd2Skip;
     }
     return d->msd2_trusted ? kMsd2Use : kMsd2Probe;
 }
@@ -1050,19 +1066,51 @@ Msd2Choice msd2_first_verdict(adlhip_device* d)
     if (d->msd2_waited) return kMsd2Probe;   // not the first time: the verdict arrives with a later call
     d->msd2_waited = true;
     if (hipStreamSynchronize(d->stream) != hipSuccess) return kMsd2Probe;
-    return msd2_decide(d) == kMsd2Use ? kMsd2Use : kMsd2Skip;
+    const Msd2Choice c = msd2_decide(d);
+    return c == kMsd2Use || c == kMsd2Dict ? c : kMsd2Skip;
 }
 
 // elem_bytes / key_bits of the array the keys are read from (AoS pairs: 8 / 32, the key is the low dword)
-int msd2_probe(adlhip_device* d, const void* keys, size_t elem_bytes, int key_bits, size_t n)
+// dict: also try to build the counting sort's dictionary (whole-key sorts of keys only)
+int msd2_probe(adlhip_device* d, const void* keys, size_t elem_bytes, int key_bits, size_t n, bool dict = false)
 {
+    adlhip::DictBlock* blk = dict ? d->d_dict : nullptr;
+    // repeats among the 16 Ki samples beyond which some value would outgrow a segment slab: D distinct values, each with n / D copies,
+    // fit while D >= the number of segments (a slab holds 1.5 x the mean); S samples of D values repeat S - D (1 - e^(-S/D)) times
+    // (taken at 3/4 of that: n / D = 1.33 x the mean still fits)
+    const double S = 16384.0, D = 0.75 * (double)(256u << msd2_seg_shift(n, false));
+    const uint32_t dup_limit = (uint32_t)(S - D * (1.0 - std::exp(-S / D)) + 600.0);   // + the table's own collisions (~500) and noise
     return launch(d, "msd2_probe", [&] {
         if (elem_bytes == 4)
             hipLaunchKernelGGL(adlhip::msd2_probe_kernel<uint32_t>, dim3(1), dim3(1024), 0, d->stream, (const uint32_t*)keys, (uint32_t)n,
-                               key_bits, d->h_fault + 11);
+                               key_bits, d->h_fault + 11, blk, dup_limit);
         else
             hipLaunchKernelGGL(adlhip::msd2_probe_kernel<uint64_t>, dim3(1), dim3(1024), 0, d->stream, (const uint64_t*)keys, (uint32_t)n,
-                               key_bits, d->h_fault + 11);
+                               key_bits, d->h_fault + 11, blk, dup_limit);
+    });
+}
+
+// Counting sort of keys that take few distinct values (dict_kernels.hpp): probe (builds the dictionary from 16 Ki sampled keys) ->
+// count (every key looked up) -> fill (the runs, in place) -- or, when a key is not in the dictionary, the cooperative LSD sort
+// inside the fill kernel.  64 Mi keys: ~0.15 ms where the one-sweep path takes 0.60-0.65 (profiles/r3_distributions.txt).
+template <typename E>
+int dict_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
+{
+    int rc = msd2_probe(d, data, sizeof(E), 8 * (int)sizeof(E), n, true);
+    if (rc) return rc;
+    constexpr size_t VEC = 16 / sizeof(E);
+    const uint32_t wgs_c = (uint32_t)std::min<size_t>(adlhip::kDictWGs, (n / VEC + adlhip::kDictNT - 1) / adlhip::kDictNT);
+    rc = launch(d, sizeof(E) == 4 ? "dict_count_u32" : "dict_count_u64", [&] {
+        hipLaunchKernelGGL(adlhip::dict_count_kernel<E>, dim3(std::max(1u, wgs_c)), dim3(adlhip::kDictNT), 0, d->stream, (const E*)data,
+                           (uint32_t)n, d->d_dict);
+    });
+    if (rc) return rc;
+    using CC = adlhip::TileCfg<E, 8, adlhip::kDictNT, 16>;   // the safety net's tile
+    const uint32_t chunk = 32768;
+    const uint32_t wgs_f = (uint32_t)std::max<size_t>(256, (n + chunk - 1) / chunk);
+    return launch(d, sizeof(E) == 4 ? "dict_fill_u32" : "dict_fill_u64", [&] {
+        hipLaunchKernelGGL(adlhip::dict_fill_kernel<E>, dim3(wgs_f), dim3(adlhip::kDictNT), CC::LDS_BYTES, d->stream, data, tmp, (uint32_t)n,
+                           d->d_dict, reinterpret_cast<uint32_t*>(work), d->d_fault, d->h_fault + 11, 8 * (int)sizeof(E), chunk);
     });
 }
 
@@ -1531,10 +1579,17 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
                        large_work_bytes(kLargeCursor, sizeof(E), n, true) <= work_bytes ? kLargeCursor : kLargeNone;
     }
     if (form != kLargeNone) {
+        // the counting sort for few distinct values: whole keys (equal keys are interchangeable), the safety net's 256 workgroups
+        const bool dict_ok = keys && sort_bits == max_bits && d->dict_path && n > kMsd2AutoMin && n < (size_t(1) << 32) &&
+                             work_bytes >= (size_t)256 * 256 * 4 + 1024;
         Msd2Choice c = msd2_decide(d);
         if (c == kMsd2Probe) {
-            if (msd2_probe(d, data, sizeof(E), sort_bits, n)) return ADLHIP_FAILURE;
+            if (msd2_probe(d, data, sizeof(E), sort_bits, n, dict_ok)) return ADLHIP_FAILURE;
             c = msd2_first_verdict(d);
+        }
+        if (c == kMsd2Dict) {
+            if (dict_ok) return dict_sort<E>(d, data, tmp, work, n);
+            c = kMsd2Skip;   // (a hint from a sort of another kind: pairs and partial sorts keep their paths)
         }
         if (c == kMsd2Use) {
             if (form == kLargeCursor) return msd2_sort<E>(d, data, tmp, work, n);
@@ -1722,6 +1777,17 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         delete d;
         return fail("cannot allocate the large sort's cursors");
     }
+    if (hipMalloc(&d->d_dict, sizeof(adlhip::DictBlock)) != hipSuccess ||
+        hipMemsetAsync(d->d_dict, 0, sizeof(adlhip::DictBlock), d->stream) != hipSuccess) {
+        if (d->d_dict) hipFree(d->d_dict);
+        hipFree(d->d_msd2);
+        hipFree(d->d_mid_hist);
+        hipFree(d->d_fault);
+        hipHostFree(d->h_fault);
+        if (own && d->stream) hipStreamDestroy(d->stream);
+        delete d;
+        return fail("cannot allocate the counting sort's dictionary");
+    }
     {   // self-test: are returning DS atomics lane-ordered on this device?  (enables "sort.rank" = 1)
         uint32_t mism = 1;
         d->lds_ordered = (run_lds_order_selftest(d, 64, &mism) == ADLHIP_SUCCESS && mism == 0) ? 1 : 0;
@@ -1775,6 +1841,7 @@ int adlhip_device_destroy(adlhip_device* d)
     if (d->fault_snap) hipEventDestroy(d->fault_snap);
     hipFree(d->d_mid_hist);
     if (d->d_msd2) hipFree(d->d_msd2);
+    if (d->d_dict) hipFree(d->d_dict);
     hipFree(d->d_fault);
     hipHostFree(d->h_fault);
     if (d->own_stream) hipStreamDestroy(d->stream);
@@ -2067,7 +2134,7 @@ int adlhip_radix_sort_soa32(adlhip_device* d, uint32_t* keys, uint32_t* vals, ui
             if (msd2_probe(d, keys, 4, sort_bits, n)) return ADLHIP_FAILURE;
             c = msd2_first_verdict(d);
         }
-        if (c == kMsd2Use) return msd2s_sort<uint64_t, false>(d, nullptr, nullptr, work, n, sort_bits, keys, vals);
+        if (c == kMsd2Use) return msd2s_sort<uint64_t, false>(d, nullptr, nullptr, work, n, sort_bits, keys, vals);   // (kMsd2Dict: keys only)
     }
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
     return run_sort<SoaBuf>(d, SoaBuf{keys, vals}, SoaBuf{tmp_keys, tmp_vals}, work, work_bytes, n, plan);
@@ -2208,6 +2275,10 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
             return fail("sort.msd2 must be 0 (off), 1 (on), 2 (always, whatever the hints say; forms by size), 3 (always the stable passes), "
                         "4 (always the cursor passes for whole keys) or 5 (always the hybrid form for whole keys)");
         d->msd2_path = value;
+    } else if (!strcmp(name, "sort.dict")) {
+        if (value != 0 && value != 1) return fail("sort.dict must be 0 (off) or 1 (counting sort for keys that take few distinct values)");
+        d->dict_path = value;
+        if (!value) d->dict_hint = false;
     } else if (!strcmp(name, "sort.binfinish")) {
         if (value < 0 || value > 2) return fail("sort.binfinish must be 0 (LSD finish), 1 (binning finish for whole u64 keys from 24 Mi keys up) or 2 (always, u32 keys too)");
         d->bin_finish = value;
@@ -2240,6 +2311,7 @@ int adlhip_get_param(adlhip_device* d, const char* name, int* value)
     else if (!strcmp(name, "sort.mid")) *value = d->mid_path;
     else if (!strcmp(name, "sort.msd2")) *value = d->msd2_path;
     else if (!strcmp(name, "sort.binfinish")) *value = d->bin_finish;
+    else if (!strcmp(name, "sort.dict")) *value = d->dict_path;
     else if (!strcmp(name, "debug.resident_wgs")) *value = d->resident_wgs;
     else if (!strcmp(name, "sort.lds_ordered")) *value = d->lds_ordered;
     else if (!strcmp(name, "profile")) *value = d->profile;

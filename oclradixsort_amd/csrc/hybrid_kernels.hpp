@@ -18,6 +18,7 @@
 
 #include "radix_kernels.hpp"
 #include "onesweep_kernels.hpp"
+#include "dict_build.hpp"
 
 namespace adlhip {
 
@@ -67,7 +68,8 @@ struct MidCoop {          // what the safety net needs beside the two arrays (ta
 template <typename E, int NT, int K>
 __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table, uint32_t* __restrict__ totals,
                                               uint32_t* bar, uint32_t* fault, unsigned char* smem, int key_bits = 32,
-                                              uint32_t target0 = 0u /* what the barrier counter has reached on entry */)
+                                              uint32_t target0 = 0u /* what the barrier counter has reached on entry */,
+                                              uint32_t wgs_arg = 0u /* workgroups that take part (the first ones of the grid); 0 = all */)
 {
     using C = TileCfg<E, 8, NT, K>;
     constexpr int NW = NT / 64;
@@ -76,7 +78,7 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
     uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + C::OFF_WSUM);
     const int tid = (int)threadIdx.x;
     const int w = tid >> 6;
-    const uint32_t wg = blockIdx.x, wgs = gridDim.x;
+    const uint32_t wg = blockIdx.x, wgs = wgs_arg ? wgs_arg : gridDim.x;
     const uint32_t tiles = (n + (uint32_t)C::TILE - 1u) / (uint32_t)C::TILE;
     const uint32_t per = (tiles + wgs - 1u) / wgs;
     const uint32_t t0 = wg * per < tiles ? wg * per : tiles;
@@ -864,8 +866,12 @@ __device__ __forceinline__ Msd2Placement msd2_placement(const uint32_t* __restri
 // saves is the safety net's 2.8 ms on the first sort of clustered / constant / low-entropy keys.  (Skew that only shows at
 // the scale of single segments is not seen here; the sort's own check remains.)
 template <typename E>
-__global__ __launch_bounds__(1024) void msd2_probe_kernel(const E* __restrict__ src, uint32_t n, int key_bits, uint32_t* host_report)
+__global__ __launch_bounds__(1024) void msd2_probe_kernel(const E* __restrict__ src, uint32_t n, int key_bits, uint32_t* host_report,
+                                                          DictBlock* __restrict__ dict /* or nullptr: no counting sort for this sort */,
+                                                          uint32_t dup_limit /* samples that may repeat an earlier one */)
 {
+    __shared__ uint32_t s_seen[8192];   // 256 Ki bits, one per hashed sample value
+    __shared__ uint32_t s_dups;
     __shared__ unsigned long long s_or[16], s_and[16];
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_top;
@@ -875,8 +881,11 @@ __global__ __launch_bounds__(1024) void msd2_probe_kernel(const E* __restrict__ 
     unsigned long long o = 0ull, a = ~0ull;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+        // sample k of 16384: somewhere inside the k-th 16384th of the array (a fixed stride would see one phase of periodic keys only)
         const unsigned long long k = (unsigned long long)(tid * 16 + i);
-        v[i] = (unsigned long long)src[(size_t)(k * (unsigned long long)n / 16384ull)] & kmask;
+        const unsigned long long cell = (unsigned long long)n / 16384ull;
+        const unsigned long long jit = cell ? ((k * 0x9E3779B97F4A7C15ull) >> 40) % cell : 0ull;
+        v[i] = (unsigned long long)src[(size_t)(k * (unsigned long long)n / 16384ull + jit)] & kmask;
         o |= v[i];
         a &= v[i];
     }
@@ -890,6 +899,8 @@ __global__ __launch_bounds__(1024) void msd2_probe_kernel(const E* __restrict__ 
         s_and[tid >> 6] = a;
     }
     if (tid < 256) s_hist[tid] = 0u;
+    for (int i = tid; i < 8192; i += 1024) s_seen[i] = 0u;
+    if (tid == 0) s_dups = 0u;
     __syncthreads();
     if (tid == 0) {
         for (int i = 1; i < 16; ++i) {
@@ -901,6 +912,19 @@ __global__ __launch_bounds__(1024) void msd2_probe_kernel(const E* __restrict__ 
         if (top < 16) top = 16;
         s_top = (uint32_t)top;
     }
+    {   // Heavy duplication -- a few thousand distinct values, each with tens of thousands of copies -- overflows the SEGMENT slabs,
+        // which no first-digit histogram shows (4096 values: every bucket is fine, the first sort went through the 2.8-ms safety
+        // net).  Samples that repeat an earlier one give it away: 16 Ki samples of keys without repeats collide ~500 times in a
+        // 256 Ki-bit table, of D distinct values S - D (1 - e^(-S/D)) times; the host passes the count at which a value outgrows a slab.
+        uint32_t mine = 0u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t h = (uint32_t)((v[i] * 0x9E3779B97F4A7C15ull) >> 46);   // 18 bits
+            const uint32_t bit = 1u << (h & 31u);
+            mine += (atomicOr(&s_seen[h >> 5], bit) & bit) ? 1u : 0u;
+        }
+        if (mine) atomicAdd(&s_dups, mine);
+    }
     __syncthreads();
     const int sb = (int)s_top - 8;
 #pragma unroll
@@ -908,9 +932,12 @@ __global__ __launch_bounds__(1024) void msd2_probe_kernel(const E* __restrict__ 
     __syncthreads();
     // mean 64 samples per bucket, sd 8; the slabs take 1.5 x the mean.  112 = + 6 sd: uniform keys are never turned away, and
     // what is turned away (1.75 x and more in some bucket) would certainly not have fitted
-    const int over = __syncthreads_or(tid < 256 && s_hist[tid & 255] > 112u);
+    const int over = __syncthreads_or((tid < 256 && s_hist[tid & 255] > 112u) || s_dups > dup_limit);
+    // few distinct values among the samples: the dictionary for the counting sort (dict_kernels.hpp), and the host is told (4)
+    uint32_t few = 0u;
+    if (dict) few = dict_build<16>(v, dict);
     // 3 = "the probe sees no obstacle" -- not the same as a sort that went through (1): only that resets the host's back-off
-    if (tid == 0) __hip_atomic_store(host_report, over ? 2u : 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(host_report, few ? 4u : (over ? 2u : 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 constexpr int kSampleWGs = 16;

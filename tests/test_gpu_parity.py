@@ -1653,3 +1653,84 @@ def test_narrow_second_digit_on_small_inputs(dev):
     finally:
         dev.setParam("sort.msd2", 1)
         p.close()
+
+
+def test_counting_sort_for_keys_with_few_distinct_values():
+    """Whole-key sorts of u32 / u64 keys that take at most 256 distinct values go to the counting sort (dict_kernels.hpp): the probe
+    builds a dictionary from 16 Ki sampled keys, every key is looked up and counted, the runs are written in place -- one read
+    and one write of the array.  A key the sample did not see sends the sort to the safety net inside the fill kernel (input
+    untouched until then); more than 256 values, pairs and partial sorts keep the ordinary paths.  Bit-exact against the oracle."""
+    rng = np.random.RandomState(11)
+    n = 3000001
+
+    def fresh():
+        d = DeviceUtils.allocate()
+        set_algo(d, (-1, 8, -1))
+        return d, Pprims()
+
+    def vals32(k):
+        return rng.randint(0, 2**32, k, dtype=np.uint64).astype(np.uint32)
+
+    for name, keys in (("all equal", np.full(n, 0x12345678, dtype=np.uint32)),
+                       ("two values", vals32(2)[rng.randint(0, 2, n)]),
+                       ("16 values", vals32(16)[rng.randint(0, 16, n)]),
+                       ("256 values, skewed (the rarest has 0.1 % of the keys)",
+                        vals32(256)[rng.choice(256, n, p=(1.0 / (np.arange(256) + 8)) / (1.0 / (np.arange(256) + 8)).sum())]),
+                       ("low byte only", rng.randint(0, 256, n).astype(np.uint32)),
+                       ("0 and 0xffffffff", np.where(rng.rand(n) < 0.3, np.uint32(0), np.uint32(0xffffffff)).astype(np.uint32))):
+        d, p = fresh()
+        try:
+            for rep in range(3):   # first sort of the handle (waits for the probe), then twice on the hint
+                got, prof = _profiled(d, lambda: gpu_sort_u32(d, p, keys))
+                assert set(prof) == {"msd2_probe", "dict_count_u32", "dict_fill_u32"}, (name, rep, prof)
+                assert np.array_equal(got, oracle.sort_u32(keys)), (name, rep)
+            d.checkFault()
+        finally:
+            p.close(); DeviceUtils.deallocate(d)
+    # u64 keys, the all-ones key among the values
+    v64 = np.concatenate([rng.randint(0, 2**63, 40, dtype=np.int64).astype(np.uint64) * np.uint64(2) + np.uint64(1),
+                          np.array([0xffffffffffffffff, 0], dtype=np.uint64)])
+    k64 = v64[rng.randint(0, v64.size, n)]
+    d, p = fresh()
+    try:
+        got, prof = _profiled(d, lambda: gpu_sort_u64(d, p, k64))
+        assert set(prof) == {"msd2_probe", "dict_count_u64", "dict_fill_u64"}, prof
+        assert np.array_equal(got, oracle.sort_u64(k64))
+        # a value the sample cannot see (one key in three million): the count kernel misses it, the fill kernel's safety net sorts
+        odd = k64.copy()
+        odd[1234567] = np.uint64(0x0123456789abcdef)
+        got, prof = _profiled(d, lambda: gpu_sort_u64(d, p, odd))
+        assert set(prof) == {"msd2_probe", "dict_count_u64", "dict_fill_u64"}, prof
+        assert prof["dict_fill_u64"][1] > 5 * prof["dict_count_u64"][1], prof   # the sort happened in there
+        assert np.array_equal(got, oracle.sort_u64(odd))
+        # ... and the handle leaves the counting sort (the report said "did not fit"); results stay right whatever comes
+        for i, k in enumerate((odd, oracle.keys_u64(n, seed=3), k64, k64, oracle.keys_u64(n, seed=4), k64)):
+            assert np.array_equal(gpu_sort_u64(d, p, k), oracle.sort_u64(k)), i
+        d.checkFault()
+    finally:
+        p.close(); DeviceUtils.deallocate(d)
+    # what does not take it: 257+ values, pairs, partial sorts, the knob
+    d, p = fresh()
+    try:
+        many = vals32(300)[rng.randint(0, 300, n)]
+        got, prof = _profiled(d, lambda: gpu_sort_u32(d, p, many))
+        assert "dict_count_u32" not in prof, prof
+        assert np.array_equal(got, oracle.sort_u32(many))
+    finally:
+        p.close(); DeviceUtils.deallocate(d)
+    d, p = fresh()
+    try:
+        few = vals32(16)[rng.randint(0, 16, n)]
+        pairs = few.astype(np.uint64) | (np.arange(n, dtype=np.uint64) << np.uint64(32))
+        got, prof = _profiled(d, lambda: gpu_sort_kv(d, p, pairs))
+        assert not any(k.startswith("dict_") for k in prof), prof
+        assert np.array_equal(got, oracle.sort_kv32(pairs))
+        got, prof = _profiled(d, lambda: gpu_sort_u32(d, p, few, 24))
+        assert not any(k.startswith("dict_") for k in prof), prof
+        assert np.array_equal(got, oracle.sort_u32_bits(few, 24))
+        d.setParam("sort.dict", 0)
+        got, prof = _profiled(d, lambda: gpu_sort_u32(d, p, few))
+        assert not any(k.startswith("dict_") for k in prof), prof
+        assert np.array_equal(got, oracle.sort_u32(few))
+    finally:
+        p.close(); DeviceUtils.deallocate(d)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sort time on non-uniform inputs (64Mi u32): sorted, reverse, all-equal, 16 distinct values, low byte only.
+"""Sort time on non-uniform inputs (64Mi u32): sorted, reverse, all-equal, 16 / 256 / 4096 distinct values, low byte only, one heavy top byte.
 Columns: the automatic choice (large sort; first sort of a fresh handle = its safety net on keys that do not fit the slabs,
 and the 8th sort = after the hint has arrived), then forced (algo, rank) pairs."""
 import os, sys
@@ -17,11 +17,15 @@ def make(kind):
     if kind == "all_equal": a = np.full(n, 0x12345678, dtype=np.uint32)
     elif kind == "16_values": a = (np.arange(n, dtype=np.uint32) * np.uint32(2654435761) >> np.uint32(28)) * np.uint32(0x11111111)
     elif kind == "low_byte": a = (np.arange(n, dtype=np.uint32) * np.uint32(2654435761)) >> np.uint32(24)
+    elif kind == "256_values": a = ((np.arange(n, dtype=np.uint32) * np.uint32(2654435761)) >> np.uint32(24)) * np.uint32(0x01010101) ^ np.uint32(0x5a5a0000)
+    elif kind == "heavy_top_byte":   # 90 % of the keys under one top byte
+        base.generate(n, seed=9); a = base.toHost(); a = np.where(np.arange(n) % 10 != 0, (a >> np.uint32(8)) | np.uint32(0x37000000), a).astype(np.uint32)
+    elif kind == "4096_values": a = ((np.arange(n, dtype=np.uint32) * np.uint32(2654435761)) >> np.uint32(20)) * np.uint32(0x00100801)
     elif kind == "reverse":
         p.radixSort(d, base, n); a = base.toHost()[::-1].copy()
     base.write(a); DeviceUtils.waitForCompletion(d)
 print("%-12s %s" % ("input", "ms/sort by (algo, rank)"))
-for kind in ("uniform", "sorted", "reverse", "all_equal", "16_values", "low_byte"):
+for kind in ("uniform", "sorted", "reverse", "all_equal", "16_values", "low_byte", "256_values", "heavy_top_byte", "4096_values"):
     make(kind)
     row = []
     d2 = DeviceUtils.allocate(); p2 = Pprims()   # a fresh handle: no hints yet
