@@ -299,16 +299,25 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      device and sorted by a cooperative LSD sort inside the same launches (correct, slower);
  *                      the handle then steers later sorts by asynchronous hints (speed only; results never
  *                      depend on them).  2 / 3 force the two- / three-launch form (tests)
- *   "sort.msd2"        1 [default] / 0: full-key sorts of 2 Mi .. 280 Mi u32 keys, 2 Mi .. 260 Mi u64 keys and
- *                      6 Mi .. 260 Mi pairs take two MSD passes into slabs of the work buffer plus one finish in
- *                      LDS (six moves of every element instead of nine); where the two digits sit is chosen on the
- *                      device from a sample of the keys.  Keys only: runs are placed with atomic cursors (equal
- *                      keys are indistinguishable); pairs: by look-back, stably.  Keys that do not fit the slabs
- *                      are detected on the device and sorted by a cooperative LSD sort inside the same launches
- *                      (correct, slower).  A handle first looks at a sample of its keys (riding along with one sort on
- *                      the per-digit passes) and uses the path only after a good report; asynchronous reports keep a
- *                      handle with unsuitable keys on the per-digit passes (speed only; results never depend on
- *                      them).  2 forces the path from 1 Mi elements (tests)
+ *   "sort.msd2"        1 [default] / 0: sorts of 2 Mi .. 280 Mi u32 keys, 2 Mi .. 260 Mi u64 keys and 1 Mi .. 260 Mi pairs on 16 or
+ *                      more bits take two MSD passes into slabs of the work buffer plus one finish in LDS (six moves of
+ *                      every element instead of nine); where the two digits sit is chosen on the device from a sample of
+ *                      the keys (inside the low sort_bits bits).  Whole keys: runs are placed with atomic cursors (equal keys
+ *                      are indistinguishable), from 96 Mi u32 / 48 Mi u64 keys the first (or both) passes by look-back;
+ *                      pairs and sorts on part of the key: by look-back, stably.  Keys that do not fit the slabs are
+ *                      detected on the device and sorted by a cooperative LSD sort inside the same launches (correct,
+ *                      slower).  A handle's first sort looks at a sample of its keys and waits for the verdict (one stream
+ *                      synchronisation per handle); afterwards asynchronous reports steer it (speed only; results never
+ *                      depend on them).  2 forces the path from 1 Mi elements (tests), 3 / 4 / 5 force its stable /
+ *                      cursor / hybrid form where it applies
+ *   "sort.binfinish"   1 [default]: whole u64 keys finish their segments by one counting pass on the top bits below the
+ *                      digits + whole-key compares inside the bins (where a segment holds ~384 keys and more); 0: the
+ *                      wave-per-segment LSD finish; 2: always, u32 keys too (tests, measurements)
+ *   "sort.dict"        1 [default] / 0: whole-key sorts of more than 2 Mi u32 / u64 keys that take at most 256 distinct values
+ *                      (the sample's verdict) are sorted by counting: dictionary, one read, one write
+ *   "debug.resident_wgs" workgroups the device certainly keeps resident at once (asked of the runtime at creation); the
+ *                      paths whose safety nets hold a grid-wide barrier over 256 workgroups are taken only when it is
+ *                      >= 256.  Setting it stands in for a small partition (tests); 0 = ask the device again
  *   "profile"          0/1: bracket every kernel launch with hipEvents (Device::toggleProfiling,
  *                          Adl/Adl.h:142, AdlKernelUtilsCL.inl:654-677) */
 int adlhip_set_param(adlhip_device* dev, const char* name, int value);
