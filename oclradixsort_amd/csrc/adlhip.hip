@@ -920,7 +920,7 @@ int mid_sort_keys(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, s
 
 // ---- large keys-only sort: two unstable MSD passes with bucket cursors + LDS finish (hybrid_kernels.hpp "sort.msd2") ------
 // u32 keys and u64 keys (equal keys are indistinguishable, so the passes need not be stable); pairs keep the stable paths.
-constexpr size_t kMsd2Min = size_t(1) << 20;                       // keys; the path works from here ("sort.msd2" = 2) ...
+constexpr size_t kMsd2Min = kSmallMax;                             // elements; the path works from here ("sort.msd2" >= 2) ...
 constexpr size_t kMsd2AutoMin = size_t(2) << 20;                   // ... and is chosen above the mid-size sort's range
                                                                    // (profiles/r2_msd2_size_curve.txt: 2.5 Mi keys 58 vs 70 us)
 constexpr size_t kMsd2MaxU32 = size_t(280) << 20;                  // mean segment n / 65536 = 4480, + 7.5 sd <= 5120
@@ -1291,7 +1291,10 @@ LargeForm large_sort_form(const adlhip_device* d, size_t elem_bytes, bool keys, 
     const bool forced = d->msd2_path >= 2;
     const bool whole = sort_bits == max_bits;
     if (!keys) return n > (forced ? kMsd2Min : kMsd2sAutoMin) && n <= kMsd2sMax ? kLargeStable : kLargeNone;
-    if (n <= (forced ? kMsd2Min : kMsd2AutoMin)) return kLargeNone;
+    // u64 keys have no mid-size sort (it serves 32-bit keys), and with the narrow second digit and the binning finish the large sort
+    // beats their per-digit passes from the one-workgroup sort's limit up: 100 K keys 78 -> 32 us, 1 Mi 117 -> 47, 2 Mi 172 -> 52
+    // (profiles/r3_small_sizes_large_sort_vs_auto.txt)
+    if (n <= (forced || elem_bytes == 8 ? kMsd2Min : kMsd2AutoMin)) return kLargeNone;
     const size_t cursor_max = elem_bytes == 4 ? kMsd2MaxU32 : kMsd2MaxU64;
     if (!whole || d->msd2_path == 3) return n <= kMsd2sMax ? kLargeStable : kLargeNone;
     if (d->msd2_path == 4) return n <= cursor_max ? kLargeCursor : kLargeNone;
