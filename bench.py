@@ -138,15 +138,19 @@ def measure_traffic(n, launch_names):
                                 acc[k][0] += float(row["Counter_Value"])
                                 acc[k][1] += 1
             for k in launch_names:
-                if acc[k][1] == 0:
-                    raise RuntimeError("no %s rows for %s" % (ctr, k))
-                res[k][ctr + "_kb"] = acc[k][0] / acc[k][1]
-                res[k]["launches_averaged"] = acc[k][1]
+                if acc[k][1]:   # (kernels of paths the sort did not take have no rows)
+                    res[k][ctr + "_kb"] = acc[k][0] / acc[k][1]
+                    res[k]["launches_averaged"] = acc[k][1]
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
     for k in launch_names:
-        res[k]["traffic_bytes_per_launch"] = int(res[k]["FETCH_SIZE_kb"] * 1024 * 2.0 + res[k]["WRITE_SIZE_kb"] * 1024)
-    return res
+        if "FETCH_SIZE_kb" in res[k] and "WRITE_SIZE_kb" in res[k]:
+            res[k]["traffic_bytes_per_launch"] = int(res[k]["FETCH_SIZE_kb"] * 1024 * 2.0 + res[k]["WRITE_SIZE_kb"] * 1024)
+            out[k] = res[k]
+    if not out:
+        raise RuntimeError("no counter rows for any of the sort's kernels")
+    return out
 
 
 def main():
@@ -168,6 +172,18 @@ def main():
     if args.pmc_child:
         pmc_child(args.n, args.steps)
         return
+
+    # roofline.traffic: the two rocprofv3 --pmc child runs come FIRST, before this process has touched the GPU (a process that
+    # has initialised the GPU must not be the one that starts other programs on this pool), and never from inside a profiler
+    pmc_traffic = {}
+    under_profiler = any(("rocprof" in os.environ.get(k, "").lower()) for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")) \
+        or any(k.startswith(("ROCPROF", "ROCPROFILER_")) for k in os.environ)
+    if (not args.no_pmc and not under_profiler and args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1
+            and args.n == N_KEYS and os.environ.get("ADLHIP_BENCH_FORCE_DIST") != "1"):
+        try:
+            pmc_traffic = measure_traffic(args.n, list(PMC_KERNEL))
+        except Exception as e:
+            pmc_traffic = {"error": repr(e)[:200]}
 
     import torch
     import torch.distributed as dist
@@ -364,15 +380,11 @@ def main():
         # HBM traffic per launch from the PMC counters, measured now: two child runs of this file under rocprofv3 (one counter
         # each, kernel trace only -- MI355X_MICROARCH.md's recipe); the committed figures of the round's profiling session
         # (profiles/*pmc_traffic.json) stand in only when rocprofv3 cannot be run here
-        traffic, traffic_src, traffic_all = None, None, {}
-        if not args.no_pmc and n == N_KEYS:
-            try:
-                names = [k for k in groups if k in PMC_KERNEL]
-                traffic_all = measure_traffic(n, names)
-                traffic = traffic_all[dom_name]["traffic_bytes_per_launch"]
-                traffic_src = "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, two child runs"
-            except Exception as e:
-                traffic_all = {"error": repr(e)[:200]}
+        traffic, traffic_src, traffic_all = None, None, pmc_traffic
+        if isinstance(traffic_all.get(dom_name), dict) and "traffic_bytes_per_launch" in traffic_all[dom_name]:
+            traffic = traffic_all[dom_name]["traffic_bytes_per_launch"]
+            traffic_src = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, two child runs of this file "
+                           "started before the timed part")
         if traffic is None:
             try:
                 import glob

@@ -1734,3 +1734,54 @@ def test_counting_sort_for_keys_with_few_distinct_values():
         assert np.array_equal(got, oracle.sort_u32(few))
     finally:
         p.close(); DeviceUtils.deallocate(d)
+
+
+def test_safety_net_beside_a_second_handle_that_keeps_the_cus_busy():
+    """The safety nets hold a grid-wide barrier over 256 workgroups.  Here they run while a second handle on another stream sorts
+    64 Mi keys over and over -- its workgroups compete for the same CUs -- on skewed keys with the large sort forced (u32 keys:
+    the net inside the offsets kernel; pairs: the stable form's; low-cardinality u64 keys with a value outside the dictionary:
+    the net inside the fill kernel): every spin is bounded, so the outcome is a right result and no fault word, never a hang."""
+    import threading
+    d1, d2 = DeviceUtils.allocate(), DeviceUtils.allocate()
+    p1, p2 = Pprims(), Pprims()
+    n = (1 << 22) + 99
+    stop = threading.Event()
+    err = []
+
+    def hammer():
+        try:
+            b = Buffer(d2, 1 << 26, np.uint32)
+            i = 0
+            while not stop.is_set():
+                b.generate(1 << 26, seed=1000 + i)
+                for _ in range(8):
+                    p2.radixSort(d2, b, 1 << 26)
+                DeviceUtils.waitForCompletion(d2)
+                i += 1
+            b.release()
+        except Exception as e:   # pragma: no cover
+            err.append(e)
+
+    t = threading.Thread(target=hammer)
+    t.start()
+    try:
+        d1.setParam("sort.msd2", 2)
+        u = oracle.keys_u32(n, seed=5)
+        skew = np.where(np.arange(n) % 10 != 0, u >> np.uint32(9), u).astype(np.uint32)
+        for rep in range(3):
+            assert np.array_equal(gpu_sort_u32(d1, p1, skew), oracle.sort_u32(skew)), rep
+            pairs = skew.astype(np.uint64) | (np.arange(n, dtype=np.uint64) << np.uint64(32))
+            assert np.array_equal(gpu_sort_kv(d1, p1, pairs), oracle.sort_kv32(pairs)), rep
+        d1.setParam("sort.msd2", 1)
+        k64 = (oracle.keys_u64(n, seed=6) % np.uint64(5)) * np.uint64(0x0101010101010101)
+        assert np.array_equal(gpu_sort_u64(d1, p1, k64), oracle.sort_u64(k64))       # counting sort
+        k64[777] = np.uint64(0x123456789)                                             # ... and its safety net
+        assert np.array_equal(gpu_sort_u64(d1, p1, k64), oracle.sort_u64(k64))
+        d1.checkFault()
+    finally:
+        stop.set()
+        t.join()
+        d1.setParam("sort.msd2", 1)
+        p1.close(); p2.close()
+        DeviceUtils.deallocate(d1); DeviceUtils.deallocate(d2)
+    assert not err, err

@@ -24,11 +24,11 @@ if [ "$PART" = a ]; then exit 0; fi
 echo "== bench"; timeout -k 10 900 python bench.py 2>&1 | tail -1 | tee $OUT/bench_n1.json
 echo "== bench, multi-GPU code path with one rank (NOT the N=1 benchmark)"; ADLHIP_BENCH_FORCE_DIST=1 timeout -k 10 600 python bench.py --no-cpu-baseline 2>&1 | tail -1 | tee $OUT/bench_forcedist.json
 echo "== rocprofv3 --kernel-trace --stats (same command)"
-cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/prof_stats.log 2>&1
+cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pmc > $OUT/prof_stats.log 2>&1
 for f in $(find $OUT/prof_stats -name "*kernel_stats.csv"); do cp $f $OUT/bench_kernel_stats.csv; head -6 $f | cut -c1-180; done
 echo "== PMC passes (separate runs, --kernel-trace only)"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-verify --no-other-configs > $OUT/pmc_$c.log 2>&1
+  timeout -k 10 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-verify --no-other-configs --no-pmc > $OUT/pmc_$c.log 2>&1
 done
 cd $GRAFT_REPO_ROOT && python3 tools/pmc_summary.py $OUT | tee $OUT/pmc_summary.txt | grep -A3 -E "onesweep_chain|msd_bucket"
-python3 tools/pmc_traffic.py $OUT $OUT/pmc_traffic.json
+python3 tools/pmc_traffic.py $OUT $OUT/pmc_traffic.json || true

@@ -10,8 +10,8 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 26
 # the dominant pass kernel: the MSD bucket pass when the run used the large keys-only sort, else the one-sweep pass
 match, profile_name = ("onesweep_chain_kernel", "unsigned int>, 8"), "onesweep_u32_8b"
 for f in glob.glob(os.path.join(root, "pmc_FETCH_SIZE", "**", "*counter_collection.csv"), recursive=True):
-    if "msd_bucket_scatter_kernel<unsigned int, 512, 32>" in open(f).read():
-        match, profile_name = ("msd_bucket_scatter_kernel<unsigned int, 512, 32>", ""), "msd2_pass_u32"
+    if "msd_bucket_scatter_kernel<unsigned int, 512, 32, 1>" in open(f).read():   # pass 1 of the large sort (round 3: a kernel name of its own)
+        match, profile_name = ("msd_bucket_scatter_kernel<unsigned int, 512, 32, 1>", ""), "msd2_pass1_u32"
 vals = {}
 kname = None
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -36,8 +36,7 @@ json.dump({
                        "the %.1f MB of keys (+ ~4 MB of status rows in the one-sweep pass) the kernel is known to read, so the factor holds for it; both counters "
                        "sit on the memory side of L2 (fabric requests), Infinity-Cache hits included" % (n * 4 / 1e6),
     "traffic_bytes_per_launch": traffic,
-    # the MSD bucket pass runs twice per sort: 4 + 4 bytes per key, then 4 + 2 (16-bit second slab): the average, as bench.py prices it
-    "algorithmic_bytes_per_launch": (2 * n * 4 + n * 6) // 2 if profile_name == "msd2_pass_u32" else 2 * n * 4,
+    "algorithmic_bytes_per_launch": 2 * n * 4,
     "how": "two separate runs of `rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py --steps 5 --warmup 1 "
            "--no-cpu-baseline --no-verify` (tools/gpu_session.sh)",
 }, open(out, "w"), indent=1)

@@ -32,7 +32,7 @@ while time.time() < t_end:
     algo = int(rng.choice([0, 0, 1, -1, -1, -1])); bits = int(rng.choice([8, 8, 8, 4])); tile = int(rng.choice([-1, -1, 0, 1, 2, 5]))
     if algo < 0: bits, tile = 8, -1   # what the automatic paths run with
     d.setParam("sort.algo", algo); d.setParam("sort.digit_bits", bits); d.setParam("sort.tile", tile)
-    d.setParam("sort.msd2", int(rng.choice([1, 1, 2])))
+    d.setParam("sort.msd2", int(rng.choice([1, 1, 1, 2, 3, 4, 5])))   # automatic (hints, probe, counting sort) or a forced form
     dist = rng.choice(["uniform", "lowbits", "fewvals", "sortedish", "shifted", "shifted"])
     shift = int(rng.randint(1, 20))
     if kind in ("u32", "soa", "kv"):
@@ -43,6 +43,13 @@ while time.time() < t_end:
         elif dist == "shifted": k >>= np.uint32(shift)
     if kind == "u32":
         b = Buffer(d, n, np.uint32); b.write(k)
+        if it % 5 == 0 and n < (1 << 22):   # a sort on part of the key (stable form of the large sort above 2 Mi keys)
+            sb = int(rng.choice([16, 20, 24, 28]))
+            p.radixSort(d, b, n, sb)
+            out = b.toHost(); b.release()
+            assert np.array_equal(out, oracle.sort_u32_bits(k, sb)), (it, kind, n, sb, dist)
+            elems += n
+            continue
         reps = int(rng.randint(1, 4))
         for _ in range(reps): p.radixSort(d, b, n)          # re-sorting sorted data stresses the low-entropy paths
         if it % 8 == 0:   # the ranking's hardware assumption, checked on another stream while these sorts run
