@@ -100,7 +100,7 @@ struct adlhip_device {
     bool dict_hint = false;                 // the last report said "few distinct values": whole-key sorts of keys go to the counting sort
     int dict_path = 1;                      // "sort.dict": counting sort for keys that take at most 256 values (dict_kernels.hpp); 0 = off
     adlhip::DictBlock* d_dict = nullptr;    // its dictionary and counters (handle-owned, counters zero between sorts)
-    uint32_t* d_msd2 = nullptr;   // the large sort's handle-owned words, allocated on first use and zero between sorts: cursors of
+    uint32_t* d_msd2 = nullptr;   // the large sort's handle-owned words, allocated with the handle and idle between sorts: cursors of
                                   // pass 1 (256, one 128-byte line each) and pass 2 (65536), overflow flag, done counter, the safety
                                   // net's barrier counter, the four sample words
     // profiling
@@ -1125,11 +1125,7 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     constexpr int K = sizeof(E) == 4 ? 32 : 16;
     constexpr int KEY_BITS = 8 * (int)sizeof(E);
     constexpr bool k32 = sizeof(E) == 4;   // profile names are kept by pointer: literals only
-    if (!d->d_msd2) {   // first use on this handle: cursors of both passes + flag + done counter, zero between sorts
-        HIPCHK(hipMalloc(&d->d_msd2, (8192 + 65536 + 64) * 4));
-        HIPCHK(hipMemsetAsync(d->d_msd2, 0, (8192 + 65536 + 64) * 4, d->stream));
-        HIPCHK(hipMemsetAsync(d->d_msd2 + 8192 + 65536 + 10, 0xff, 8, d->stream));   // the sample's AND words
-    }
+    // d_msd2 (allocated at device creation): cursors of both passes + flag + done counter + sample words, idle values between sorts
     uint32_t* cur_a = d->d_msd2;            // 256 cursors, one 128-byte line each
     uint32_t* cur_b = d->d_msd2 + 8192;     // 65536 cursors, packed (16 atomics each per sort)
     uint32_t* flag = d->d_msd2 + 8192 + 65536;
@@ -1364,11 +1360,6 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
     constexpr bool k32 = sizeof(E) == 4;
     constexpr int KEY_BITS = KEY64 ? 64 : 32;
     const bool whole = sort_bits == KEY_BITS;
-    if (!d->d_msd2) {
-        HIPCHK(hipMalloc(&d->d_msd2, (8192 + 65536 + 64) * 4));
-        HIPCHK(hipMemsetAsync(d->d_msd2, 0, (8192 + 65536 + 64) * 4, d->stream));
-        HIPCHK(hipMemsetAsync(d->d_msd2 + 8192 + 65536 + 10, 0xff, 8, d->stream));
-    }
     uint32_t* flag = d->d_msd2 + 8192 + 65536;
     uint32_t* done = flag + 1;
     uint32_t* bar = flag + 2;
@@ -1771,7 +1762,8 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
     // the large sort's handle-owned words (cursors, flags: 270 KB), zero between sorts -- allocated here rather than by a handle's
     // first large sort, which then only has its probe to wait for
     if (hipMalloc(&d->d_msd2, (8192 + 65536 + 64) * 4) != hipSuccess ||
-        hipMemsetAsync(d->d_msd2, 0, (8192 + 65536 + 64) * 4, d->stream) != hipSuccess) {
+        hipMemsetAsync(d->d_msd2, 0, (8192 + 65536 + 64) * 4, d->stream) != hipSuccess ||
+        hipMemsetAsync(d->d_msd2 + 8192 + 65536 + 10, 0xff, 8, d->stream) != hipSuccess) {   // the sample's AND words: all ones when idle
         if (d->d_msd2) hipFree(d->d_msd2);
         hipFree(d->d_mid_hist);
         hipFree(d->d_fault);

@@ -73,6 +73,11 @@ __device__ __forceinline__ uint32_t dict_build(const unsigned long long (&smp)[P
     }
     __syncthreads();
     const uint32_t distinct = s_cnt + s_maxkey;
+    if (tid == 0) {   // whatever the samples say: the count kernel's flags and the safety net's barrier counter start from zero (a
+        blk->miss = 0u;   // net that ran before leaves the counter at a multiple of 256, and a barrier that starts there lets
+        blk->done = 0u;   // everyone through at once)
+        blk->bar = 0u;
+    }
     if (distinct == 0u || distinct > (uint32_t)kDictMax) {
         if (tid == 0) blk->n_values = 0u;
         return 0u;
@@ -106,12 +111,7 @@ __device__ __forceinline__ uint32_t dict_build(const unsigned long long (&smp)[P
             }
         }
     }
-    if (tid == 0) {
-        blk->n_values = distinct;
-        blk->miss = 0u;
-        blk->done = 0u;
-        blk->bar = 0u;
-    }
+    if (tid == 0) blk->n_values = distinct;
     return distinct;
 }
 

@@ -1785,3 +1785,53 @@ def test_safety_net_beside_a_second_handle_that_keeps_the_cus_busy():
         p1.close(); p2.close()
         DeviceUtils.deallocate(d1); DeviceUtils.deallocate(d2)
     assert not err, err
+
+
+def test_first_sort_of_a_fresh_handle_places_its_digits_from_the_sample():
+    """The sample words of the large sort idle at or = 0 / and = ~0; a fresh handle must start from those values too, or its
+    first sort of keys that leave their top bits constant puts the first digit on those bits, overflows and goes through the
+    safety net (right result, 7 x the time).  The offsets kernel is where the net would run: it must take microseconds."""
+    n = (1 << 22) + 11
+    keys = (oracle.keys_u32(n, seed=4) >> np.uint32(3)) | np.uint32(0xa0000000)   # one eighth of the key range
+    d = DeviceUtils.allocate()
+    p = Pprims()
+    try:
+        d.setParam("sort.msd2", 4)
+        got, prof = _profiled(d, lambda: gpu_sort_u32(d, p, keys))
+        assert "msd2_offsets" in prof and prof["msd2_offsets"][1] < 0.1, prof
+        assert np.array_equal(got, oracle.sort_u32(keys))
+    finally:
+        p.close(); DeviceUtils.deallocate(d)
+
+
+def test_counting_sort_hint_then_other_keys_back_to_back():
+    """A handle on the counting sort's hint gets keys that are nothing like that, several sorts queued back to back before any
+    report can arrive: every one of them finds no dictionary and runs the safety net inside the fill kernel -- whose barrier counter
+    must start from zero each time (a net that ran before leaves it at a multiple of 256).  Found by tools/stress.py."""
+    n = (1 << 22) + 321
+    d = DeviceUtils.allocate()
+    set_algo(d, (-1, 8, -1))
+    p = Pprims()
+    try:
+        few = (oracle.keys_u32(n, seed=1) % np.uint32(5)) * np.uint32(0x01010101)
+        got, prof = _profiled(d, lambda: gpu_sort_u32(d, p, few))
+        assert "dict_fill_u32" in prof, prof
+        assert np.array_equal(got, oracle.sort_u32(few))
+        for kind in ("u32", "u64"):
+            keys = oracle.keys_u32(n, seed=2) if kind == "u32" else oracle.keys_u64(n, seed=2)
+            bufs = [Buffer(d, n, keys.dtype) for _ in range(4)]
+            for b in bufs:
+                b.write(keys)
+            DeviceUtils.waitForCompletion(d)
+            # re-arm the hint (the uniform sorts below will have dropped it)
+            assert np.array_equal(gpu_sort_u32(d, p, few), oracle.sort_u32(few))
+            assert np.array_equal(gpu_sort_u32(d, p, few), oracle.sort_u32(few))
+            for b in bufs:                        # four sorts queued without a synchronisation in between
+                (p.radixSort if kind == "u32" else p.radixSort64)(d, b, n)
+            want = oracle.sort_u32(keys) if kind == "u32" else oracle.sort_u64(keys)
+            for i, b in enumerate(bufs):
+                assert np.array_equal(b.toHost(), want), (kind, i)
+                b.release()
+        d.checkFault()
+    finally:
+        p.close(); DeviceUtils.deallocate(d)

@@ -14,7 +14,10 @@ import oracle
 import ctypes
 from oclradixsort_amd import Buffer, DeviceUtils, Pprims, _lib
 from oclradixsort_amd._lib import check
-ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=60.0); args = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=60.0)
+ap.add_argument("--skip-before", type=int, default=0, help="replay: draw the first iterations without running them")
+ap.add_argument("--stop-after", type=int, default=1 << 30); ap.add_argument("--verbose", action="store_true"); args = ap.parse_args()
+skip_before, verbose = args.skip_before, args.verbose
 d = DeviceUtils.allocate(); p = Pprims()
 d2 = DeviceUtils.allocate(); selftests = 0
 rng = np.random.RandomState(2026)
@@ -23,7 +26,7 @@ it = 0; elems = 0; t_mark = time.time()
 def checks(a):
     a64 = a.astype(np.uint64)
     return int(a64.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(a64)) if a.size else 0
-while time.time() < t_end:
+while time.time() < t_end and it < args.stop_after:
     it += 1
     kind = rng.choice(["u32", "kv", "u64", "soa"])
     n = int(2 ** rng.uniform(10, 25.5)) + int(rng.randint(0, 1000))
@@ -35,6 +38,13 @@ while time.time() < t_end:
     d.setParam("sort.msd2", int(rng.choice([1, 1, 1, 2, 3, 4, 5])))   # automatic (hints, probe, counting sort) or a forced form
     dist = rng.choice(["uniform", "lowbits", "fewvals", "sortedish", "shifted", "shifted"])
     shift = int(rng.randint(1, 20))
+    msd2_mode = d.getParam("sort.msd2")
+    if it < skip_before:   # replay: only the draws of the generator (they do not depend on any result)
+        if kind == "u32":
+            if it % 5 == 0 and n < (1 << 22): rng.choice([16, 20, 24, 28])
+            else: rng.randint(1, 4)
+        continue
+    if verbose: print("it %d %s n=%d algo=%d bits=%d tile=%d msd2=%d dist=%s shift=%d" % (it, kind, n, algo, bits, tile, msd2_mode, dist, shift), flush=True)
     if kind in ("u32", "soa", "kv"):
         k = oracle.keys_u32(n, seed=it)
         if dist == "lowbits": k &= np.uint32(0xffff)
