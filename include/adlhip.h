@@ -355,6 +355,13 @@ int adlhip_probe_read(adlhip_device* dev, const void* d_src, size_t bytes, void*
  * handle while sorts run on the first.  No reference counterpart. */
 int adlhip_selftest_lds_order(adlhip_device* dev, int workgroups, uint32_t* mismatches);
 
+/* Self-test of the key probe's sampling (hybrid_kernels.hpp probe_sample_index): computes, on the device, the 16384 positions
+ * the probe would read in an array of n elements (16384 <= n) and BLOCKS until *max_index holds the largest of them (must be
+ * < n) and *out_of_cell the number of positions outside their 16384th of the array (must be 0).  A regression hook: a
+ * compiler expansion of an integer remainder once sent 13 of the samples 64 MiB past a 7.7 Mi-key array.  No reference
+ * counterpart. */
+int adlhip_selftest_probe_positions(adlhip_device* dev, size_t n, uint32_t* max_index, uint32_t* out_of_cell);
+
 const char* adlhip_version(void);
 
 #ifdef __cplusplus

@@ -91,6 +91,7 @@ SIGNATURES = {
     "adlhip_probe_copy": (_I, [_VP, _VP, _VP, _SZ]),
     "adlhip_probe_read": (_I, [_VP, _VP, _SZ, _VP]),
     "adlhip_selftest_lds_order": (_I, [_VP, _I, ctypes.POINTER(ctypes.c_uint32)]),
+    "adlhip_selftest_probe_positions": (_I, [_VP, _SZ, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     "adlhip_version": (ctypes.c_char_p, []),
 }
 

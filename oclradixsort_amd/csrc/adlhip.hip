@@ -144,6 +144,12 @@ hipEvent_t take_event(adlhip_device* d)
 }
 
 // Launch wrapper: optional hipEvent bracket per launch ("profile" = 1), error check after.
+inline int trace_level()
+{
+    static const int level = getenv("ADLHIP_TRACE") ? atoi(getenv("ADLHIP_TRACE")) : 0;
+    return level;
+}
+
 template <typename F>
 int launch(adlhip_device* d, const char* name, F&& f)
 {
@@ -154,9 +160,15 @@ int launch(adlhip_device* d, const char* name, F&& f)
         if (!e0 || !e1) return fail("hipEventCreate failed");
         HIPCHK(hipEventRecord(e0, d->stream));
     }
+    // ADLHIP_TRACE=1 (debugging aid): name every launch on stderr and wait for it, so that the last line before a GPU fault
+    // names the kernel that raised it
+    // (ADLHIP_TRACE=2: names only, nothing waits)
+    static const int trace = trace_level();
+    if (trace) fprintf(stderr, "[adlhip] launch %s\n", name), fflush(stderr);
     f();
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("launch of %s failed: %s", name, hipGetErrorString(e));
+    if (trace == 1 && (e = hipStreamSynchronize(d->stream)) != hipSuccess) return fail("%s: %s", name, hipGetErrorString(e));
     if (d->profile) {
         HIPCHK(hipEventRecord(e1, d->stream));
         d->pending.push_back({name, e0, e1});
@@ -1555,6 +1567,9 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
     if (bind(d)) return ADLHIP_FAILURE;
     if (check_sort_args(d, elem_kind, data, tmp, work, work_bytes, n, sort_bits, max_bits)) return ADLHIP_FAILURE;
     if (n == 0) return ADLHIP_SUCCESS;
+    if (trace_level())
+        fprintf(stderr, "[adlhip] sort kind %d n %zu bits %d data %p tmp %p work %p + %zu\n", elem_kind, n, sort_bits, (void*)data, (void*)tmp,
+                work, work_bytes);
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
     if (d->sort_algo < 0 && n <= kSmallMax) return small_sort<E>(d, data, n, plan);   // one workgroup, one launch
     if (mid_eligible(d, sizeof(E), n, sort_bits, max_bits) && mid_layout(n).total <= work_bytes) {
@@ -1711,6 +1726,27 @@ int adlhip_selftest_lds_order(adlhip_device* d, int workgroups, uint32_t* mismat
     return run_lds_order_selftest(d, workgroups, mismatches);
 }
 
+int adlhip_selftest_probe_positions(adlhip_device* d, size_t n, uint32_t* max_index, uint32_t* out_of_cell)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!max_index || !out_of_cell) return fail("null out pointer");
+    if (n < 16384 || n > kMaxElems) return fail("selftest: n must be in [16384, %zu]", (size_t)kMaxElems);
+    // two words of the dictionary block's count[] (idle between sorts: zero) serve as the result
+    uint32_t* res = d->d_dict->count;
+    HIPCHK(hipMemsetAsync(res, 0, 8, d->stream));
+    int rc = launch(d, "probe_positions_selftest", [&] {
+        hipLaunchKernelGGL(adlhip::probe_positions_selftest_kernel, dim3(1), dim3(1024), 0, d->stream, (uint32_t)n, res);
+    });
+    if (rc) return rc;
+    uint32_t h[2] = {0u, 0u};
+    HIPCHK(hipMemcpyAsync(h, res, 8, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipMemsetAsync(res, 0, 8, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    *max_index = h[0];
+    *out_of_cell = h[1];
+    return ADLHIP_SUCCESS;
+}
+
 static int create_common(int device_idx, void* stream, bool own, adlhip_device** out)
 {
     if (!out) return fail("null out pointer");
@@ -1783,6 +1819,9 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         delete d;
         return fail("cannot allocate the counting sort's dictionary");
     }
+    if (trace_level())
+        fprintf(stderr, "[adlhip] handle %p: d_fault %p h_fault %p d_mid_hist %p d_msd2 %p d_dict %p\n", (void*)d, (void*)d->d_fault,
+                (void*)d->h_fault, (void*)d->d_mid_hist, (void*)d->d_msd2, (void*)d->d_dict);
     {   // self-test: are returning DS atomics lane-ordered on this device?  (enables "sort.rank" = 1)
         uint32_t mism = 1;
         d->lds_ordered = (run_lds_order_selftest(d, 64, &mism) == ADLHIP_SUCCESS && mism == 0) ? 1 : 0;
@@ -1925,6 +1964,7 @@ int adlhip_malloc(adlhip_device* d, size_t bytes, void** dptr)
         return fail("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
     d->used_bytes += bytes;
+    if (trace_level()) fprintf(stderr, "[adlhip] malloc %p + %zu\n", *dptr, bytes);
     return ADLHIP_SUCCESS;
 }
 
@@ -1932,6 +1972,7 @@ int adlhip_free(adlhip_device* d, void* dptr, size_t bytes)
 {
     if (bind(d)) return ADLHIP_FAILURE;
     if (!dptr) return ADLHIP_SUCCESS;
+    if (trace_level()) fprintf(stderr, "[adlhip] free %p + %zu\n", dptr, bytes);
     HIPCHK(hipStreamSynchronize(d->stream));   // queued work may still use it
     HIPCHK(hipFree(dptr));
     d->used_bytes -= std::min<uint64_t>(bytes, d->used_bytes);
@@ -1942,6 +1983,7 @@ int adlhip_memcpy_h2d(adlhip_device* d, void* dst, const void* src, size_t bytes
 {
     if (bind(d)) return ADLHIP_FAILURE;
     if (bytes == 0) return ADLHIP_SUCCESS;
+    if (trace_level()) fprintf(stderr, "[adlhip] h2d %p <- %p + %zu\n", dst, src, bytes);
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream));
     return ADLHIP_SUCCESS;
 }
@@ -1950,6 +1992,7 @@ int adlhip_memcpy_d2h(adlhip_device* d, void* dst, const void* src, size_t bytes
 {
     if (bind(d)) return ADLHIP_FAILURE;
     if (bytes == 0) return ADLHIP_SUCCESS;
+    if (trace_level()) fprintf(stderr, "[adlhip] d2h %p <- %p + %zu\n", dst, src, bytes);
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, d->stream));
     return ADLHIP_SUCCESS;
 }

@@ -858,6 +858,36 @@ __device__ __forceinline__ Msd2Placement msd2_placement(const uint32_t* __restri
     p.prefix = p.top < 64 ? (o >> p.top) : 0ull;
     return p;
 }
+// Where the probe reads sample k of 16384 (n >= 16384): somewhere inside the k-th 16384th of the array (a fixed stride would see
+// one phase of periodic keys only).  The offset inside the cell is a 24-bit hash scaled by multiply-and-shift, NOT `hash % cell`:
+// the compiler expands a remainder of operands it knows to fit 24 bits through float (v_rcp_iflag_f32, one upward correction),
+// which overshoots the quotient for some operands (n = 7726351: 13 of the 16384 samples), the "remainder" wraps to ~2^24 and
+// the load lands 64 MiB past the array -- a memory fault whenever nothing is mapped there (found by tools/stress.py;
+// adlhip_selftest_probe_positions checks the positions on the device).
+__device__ __forceinline__ size_t probe_sample_index(uint32_t k, uint32_t n)
+{
+    const uint32_t cell = n >> 14;                                                           // < 2^18
+    const uint32_t hash24 = (uint32_t)(((unsigned long long)k * 0x9E3779B97F4A7C15ull) >> 40);
+    const uint32_t jit = (uint32_t)(((unsigned long long)hash24 * cell) >> 24);              // in [0, cell)
+    unsigned long long at = (unsigned long long)k * (unsigned long long)n / 16384ull + jit;
+    if (at >= n) at = n - 1u;   // cannot happen (k n / 16384 + cell - 1 <= n - 1); the load stays inside the array whatever
+    return (size_t)at;
+}
+// self-test: out[0] = the largest position any of the 16384 samples reads for this n, out[1] = positions outside their cell
+__global__ __launch_bounds__(1024) void probe_positions_selftest_kernel(uint32_t n, uint32_t* __restrict__ out)
+{
+    uint32_t hi = 0u, bad = 0u;
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t k = threadIdx.x * 16u + (uint32_t)i;
+        const unsigned long long at = probe_sample_index(k, n);
+        const unsigned long long lo = (unsigned long long)k * n / 16384ull, up = (unsigned long long)(k + 1u) * n / 16384ull;
+        if (at < lo || at >= (up > lo ? up : lo + 1ull) || at >= n) ++bad;
+        hi = at > hi ? (uint32_t)at : hi;
+    }
+    atomicMax(out + 0, hi);
+    if (bad) atomicAdd(out + 1, bad);
+}
+
 // Before a device handle trusts the large sort with its keys it looks at them once: ONE workgroup samples 16 Ki keys, places
 // the first digit exactly as the sort would (msd2_placement's rule on the sample's OR / AND) and counts the samples per bucket;
 // a bucket with 1.75 x the mean (64 samples, + 6 sd) would not fit its slab.  The verdict goes into the same pinned
@@ -882,10 +912,7 @@ __global__ __launch_bounds__(1024) void msd2_probe_kernel(const E* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         // sample k of 16384: somewhere inside the k-th 16384th of the array (a fixed stride would see one phase of periodic keys only)
-        const unsigned long long k = (unsigned long long)(tid * 16 + i);
-        const unsigned long long cell = (unsigned long long)n / 16384ull;
-        const unsigned long long jit = cell ? ((k * 0x9E3779B97F4A7C15ull) >> 40) % cell : 0ull;
-        v[i] = (unsigned long long)src[(size_t)(k * (unsigned long long)n / 16384ull + jit)] & kmask;
+        v[i] = (unsigned long long)src[probe_sample_index((uint32_t)(tid * 16 + i), n)] & kmask;
         o |= v[i];
         a &= v[i];
     }

@@ -1835,3 +1835,38 @@ def test_counting_sort_hint_then_other_keys_back_to_back():
         d.checkFault()
     finally:
         p.close(); DeviceUtils.deallocate(d)
+
+
+@pytest.mark.gpu
+def test_probe_sample_positions_stay_inside_the_array(dev):
+    """The key probe reads 16384 samples, one somewhere inside every 16384th of the array.  The first version took the offset inside
+    the cell as `hash % cell`; the compiler expands that remainder (operands known to fit 24 bits) through float and overshoots
+    for some operands, so that 13 samples of a 7726351-key array were read 64 MiB past its end -- a GPU memory fault when nothing
+    is mapped there (tools/stress.py, iteration 2225).  adlhip_selftest_probe_positions evaluates the device code's positions."""
+    lib = _lib.load()
+    rng = np.random.RandomState(5)
+    sizes = [16384, 16385, 20543, 730669, 7726351, (1 << 24) - 1, 1 << 26, (1 << 28) + 12345, (1 << 30) + 7]
+    sizes += [int(2 ** rng.uniform(14.1, 30)) for _ in range(300)]
+    for n in sizes:
+        hi, bad = ctypes.c_uint32(0), ctypes.c_uint32(1)
+        check(lib.adlhip_selftest_probe_positions(dev._h, n, ctypes.byref(hi), ctypes.byref(bad)), "probe positions")
+        assert bad.value == 0 and hi.value < n, (n, hi.value, bad.value)
+        assert hi.value >= n - 2 * (n // 16384) - 2, (n, hi.value)   # the last cell is sampled too
+    # the sorts that raised the fault: fresh handles, so the probe runs
+    for kind, n, shift in (("u32", 7726351, 16), ("u64", 730669, 10)):
+        d = DeviceUtils.allocate()
+        set_algo(d, (-1, 8, -1))
+        p = Pprims()
+        try:
+            if kind == "u32":
+                k = oracle.keys_u32(n, seed=2225) >> np.uint32(shift)
+                got, prof = _profiled(d, lambda: gpu_sort_u32(d, p, k))
+                assert np.array_equal(got, oracle.sort_u32(k))
+            else:
+                k = oracle.keys_u64(n, seed=77) >> np.uint64(shift)
+                got, prof = _profiled(d, lambda: gpu_sort_u64(d, p, k))
+                assert np.array_equal(got, oracle.sort_u64(k))
+            assert "msd2_probe" in prof, prof
+            d.checkFault()
+        finally:
+            p.close(); DeviceUtils.deallocate(d)
