@@ -49,6 +49,30 @@ def test_library_contains_gfx950_code_object():
     assert archs == {b"gfx950"}, archs
 
 
+def test_no_float_expanded_integer_division_in_the_device_code(tmp_path):
+    """The compiler expands `a / b` and `a % b` of integers it knows to fit 24 bits through float (v_rcp_iflag_f32, v_trunc_f32, one
+    upward correction).  For some operands the quotient comes out one too high and the remainder wraps -- that sent the key
+    probe's loads 64 MiB past its array (tools/stress.py).  The 32-bit expansion (v_mul_hi_u32 corrections)
+    is exact and is allowed; the 24-bit one is recognisable by its v_trunc_f32, which nothing else in this library uses."""
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    data = open(_lib.LIB_PATH, "rb").read()
+    at = [m.start() for m in re.finditer(b"\x7fELF", data) if int.from_bytes(data[m.start() + 18:m.start() + 20], "little") == 224]
+    assert at, "no AMDGPU code object inside the library"
+    co = tmp_path / "device.co"
+    co.write_bytes(data[at[0]:])
+    out = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True).stdout
+    assert out.count("s_endpgm") >= 50, "disassembly failed"
+    kernel, hits = None, []
+    for line in out.splitlines():
+        if line.endswith(">:"):
+            kernel = line.split("<", 1)[1][:-2]
+        elif "v_trunc_f32" in line:
+            hits.append(kernel)
+    assert not hits, sorted(set(hits))
+
+
 def test_header_compiles_as_plain_c(tmp_path):
     src = tmp_path / "t.c"
     src.write_text('#include "adlhip.h"\nint main(void){ adlhip_info i; (void)i; return ADLHIP_SUCCESS; }\n')
