@@ -142,13 +142,18 @@ int adlhip_unmap(adlhip_device* dev, void* dptr, void* hptr, size_t bytes);
 int adlhip_radix_sort_scratch_bytes(adlhip_device* dev, int elem_kind, size_t n,
                                     size_t* tmp_bytes, size_t* work_bytes);
 
-/* The same for a sort on `sort_bits` bits, at one of two levels:
+/* The same for a sort on `sort_bits` bits, at one of three levels (sizes: level 0 <= level 2 <= level 1):
  *   level 0: the minimum -- the reference's own contract (Pprims.cpp:332-337: the n-element partner array and a digit table of
  *            a few KiB).  Every sort entry point accepts a work buffer of this size; the sort then runs the per-digit
  *            three-kernel passes (64 Mi u32 keys: 75 instead of 164 Gkeys/s).
  *   level 1: full speed -- what adlhip_radix_sort_scratch_bytes reports for whole keys.  A sort on fewer bits than the key has
  *            takes the stable form of the large sort, whose second slab cannot shrink to 16 bits per key, and so needs more.
- * With a work buffer between the two, every path checks its own need and the sort takes the fastest one that fits. */
+ *   level 2: lean -- whole u32 / u64 keys keep the large sort (cursor form) with 12 % instead of 50 % of head-room in the
+ *            first pass's bucket slabs: 64 Mi u32 keys 307 MB of work instead of 451, same speed on keys spread evenly over
+ *            their range; keys whose density varies by more than ~10 % from one 256th of the range to the next go through
+ *            the safety net once and then, by the handle's hints, to the one-sweep passes.  Pairs, SoA and sorts on part of
+ *            the key get the one-sweep passes' size (their slabs cannot shrink this way).
+ * With a work buffer between the levels, every path checks its own need and the sort takes the fastest one that fits. */
 int adlhip_radix_sort_scratch_bytes_for(adlhip_device* dev, int elem_kind, size_t n, int sort_bits, int level,
                                         size_t* tmp_bytes, size_t* work_bytes);
 

@@ -998,13 +998,19 @@ uint32_t msd2_seg_shift(size_t n, bool bin_finish)
 }
 
 
-Msd2Layout msd2_layout(size_t n, size_t elem_bytes)
+// head-room of a first-pass bucket slab over the mean bucket, in per cent: 50 at full speed; the lean work size
+// (adlhip_radix_sort_scratch_bytes_for, level 2) takes 12 -- 64 Mi u32 keys then need 307 MB of work instead of 451, and keys whose
+// density varies by more than ~10 % over the key range go to the safety net (and, by the handle's hints, to the one-sweep passes)
+constexpr int kFullHeadroomPct = 50, kLeanHeadroomPct = 12;
+
+Msd2Layout msd2_layout(size_t n, size_t elem_bytes, int headroom_pct = kFullHeadroomPct)
 {
     Msd2Layout L;
     const uint32_t tile = elem_bytes == 4 ? 16384u : 8192u;   // TileCfg<E, 8, 512, 32 | 16>
     // mean bucket + 50 % + 4096: the head-room of the segment slabs below (1536 for a mean of 1024), so that keys whose density
     // varies by up to ~45 % over the key range stay on this path (with + 3 % any mild skew went to the safety net)
-    static const int headroom_pct = getenv("ADLHIP_SLAB_A_HEADROOM_PCT") ? atoi(getenv("ADLHIP_SLAB_A_HEADROOM_PCT")) : 50;   // A/B only
+    static const int env_pct = getenv("ADLHIP_SLAB_A_HEADROOM_PCT") ? atoi(getenv("ADLHIP_SLAB_A_HEADROOM_PCT")) : -1;   // A/B only
+    if (headroom_pct == kFullHeadroomPct && env_pct >= 0) headroom_pct = env_pct;
     L.stride_a = (uint32_t)align_up(n / 256 + (n / 256) * (size_t)headroom_pct / 100 + 4096, 64);
     L.seg_shift = msd2_seg_shift(n, elem_bytes == 8);   // the cursor form sorts whole keys: 8-byte elements = u64 keys
     L.slots = 256u << L.seg_shift;
@@ -1132,7 +1138,7 @@ int launch_large_finish(adlhip_device* d, const E* slab_b, E* out, uint32_t* out
 bool use_bin_finish(const adlhip_device* d, size_t elem_bytes, bool key64, size_t n, bool whole_keys);
 
 template <typename E>
-int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
+int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int headroom_pct = kFullHeadroomPct)
 {
     constexpr int K = sizeof(E) == 4 ? 32 : 16;
     constexpr int KEY_BITS = 8 * (int)sizeof(E);
@@ -1143,7 +1149,7 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
     uint32_t* flag = d->d_msd2 + 8192 + 65536;
     uint32_t* done = flag + 1;
     uint32_t* sample = flag + 8;            // or lo, or hi, and lo, and hi (hybrid_kernels.hpp msd2_placement)
-    const Msd2Layout L = msd2_layout(n, sizeof(E));
+    const Msd2Layout L = msd2_layout(n, sizeof(E), headroom_pct);
     char* wb = reinterpret_cast<char*>(work);
     uint32_t* mode = reinterpret_cast<uint32_t*>(wb + L.off_mode);
     uint32_t* seg_cnt = reinterpret_cast<uint32_t*>(wb + L.off_cnt);
@@ -1479,7 +1485,9 @@ size_t large_work_bytes(LargeForm form, size_t elem_bytes, size_t n, bool whole)
 
 // Work bytes with which a sort of n elements on sort_bits bits runs at full speed (level 1), or runs at all (level 0: the
 // per-digit three-kernel passes -- the reference's own contract: a table of a few KiB beside the n-element partner array,
-// Pprims.cpp:332-337).  With anything in between, every path checks its own need and the sort takes the fastest one that fits.
+// Pprims.cpp:332-337), or keeps the large sort for whole u32 / u64 keys with 12 % instead of 50 % of head-room in the first
+// slabs (level 2, "lean": 64 Mi u32 keys 307 MB instead of 451).  With anything in between, every path checks its own need and
+// the sort takes the fastest one that fits.
 size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n, int sort_bits, int level)
 {
     const size_t a = work_bytes_three_kernel(d, n);
@@ -1497,8 +1505,12 @@ size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n, int s
     const bool whole = sort_bits == max_bits;
     const bool keys = elem_kind == ADLHIP_ELEM_U32 || elem_kind == ADLHIP_ELEM_U64;
     if (n > kMsd2Min && sort_bits >= 16) {
-        if (n <= kMsd2sMax) e = msd2s_layout(n, eb, eb == 4 && whole).total;
-        if (keys && whole && n <= (eb == 4 ? kMsd2MaxU32 : kMsd2MaxU64)) e = std::max(e, msd2_layout(n, eb).total);
+        if (level == 2) {   // lean: whole keys keep the cursor form with little head-room; every other sort runs the one-sweep passes
+            if (keys && whole && n <= (eb == 4 ? kMsd2MaxU32 : kMsd2MaxU64)) e = msd2_layout(n, eb, kLeanHeadroomPct).total;
+        } else {
+            if (n <= kMsd2sMax) e = msd2s_layout(n, eb, eb == 4 && whole).total;
+            if (keys && whole && n <= (eb == 4 ? kMsd2MaxU32 : kMsd2MaxU64)) e = std::max(e, msd2_layout(n, eb).total);
+        }
     }
     return std::max(std::max(a, b), std::max(c, e));
 }
@@ -1581,11 +1593,20 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
     }
     const bool keys = (int)sizeof(E) * 8 == max_bits;
     LargeForm form = large_sort_form(d, sizeof(E), keys, n, sort_bits, max_bits);
+    int headroom = kFullHeadroomPct;
     if (form != kLargeNone && large_work_bytes(form, sizeof(E), n, sort_bits == max_bits) > work_bytes) {
-        // the slabs do not fit the caller's work buffer: whole keys may still fit the cursor form (its second slab is smaller)
+        // the slabs do not fit the caller's work buffer: whole keys may still fit the cursor form (its second slab is smaller),
+        // at full head-room or at the lean one (level 2 of adlhip_radix_sort_scratch_bytes_for)
         const bool whole = sort_bits == max_bits;
-        form = keys && whole && n <= (sizeof(E) == 4 ? kMsd2MaxU32 : kMsd2MaxU64) &&
-                       large_work_bytes(kLargeCursor, sizeof(E), n, true) <= work_bytes ? kLargeCursor : kLargeNone;
+        const bool cursor_ok = keys && whole && n <= (sizeof(E) == 4 ? kMsd2MaxU32 : kMsd2MaxU64);
+        if (cursor_ok && large_work_bytes(kLargeCursor, sizeof(E), n, true) <= work_bytes) {
+            form = kLargeCursor;
+        } else if (cursor_ok && msd2_layout(n, sizeof(E), kLeanHeadroomPct).total <= work_bytes) {
+            form = kLargeCursor;
+            headroom = kLeanHeadroomPct;
+        } else {
+            form = kLargeNone;
+        }
     }
     if (form != kLargeNone) {
         // the counting sort for few distinct values: whole keys (equal keys are interchangeable), the safety net's 256 workgroups
@@ -1601,7 +1622,7 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
             c = kMsd2Skip;   // (a hint from a sort of another kind: pairs and partial sorts keep their paths)
         }
         if (c == kMsd2Use) {
-            if (form == kLargeCursor) return msd2_sort<E>(d, data, tmp, work, n);
+            if (form == kLargeCursor) return msd2_sort<E>(d, data, tmp, work, n, headroom);
             const bool hybrid = form == kLargeHybrid;
             if constexpr (sizeof(E) == 4) {
                 return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits, nullptr, nullptr, hybrid);
@@ -2130,7 +2151,7 @@ int adlhip_radix_sort_scratch_bytes_for(adlhip_device* d, int elem_kind, size_t 
     if (elem_kind < ADLHIP_ELEM_U32 || elem_kind > ADLHIP_ELEM_SOA32) return fail("bad element kind %d", elem_kind);
     const int max_bits = elem_kind == ADLHIP_ELEM_U64 ? 64 : 32;
     if (sort_bits < 4 || sort_bits > max_bits || (sort_bits & 3)) return fail("sort_bits must be a multiple of 4 in [4,%d], got %d", max_bits, sort_bits);
-    if (level != 0 && level != 1) return fail("level must be 0 (minimum) or 1 (full speed), got %d", level);
+    if (level < 0 || level > 2) return fail("level must be 0 (minimum), 1 (full speed) or 2 (lean), got %d", level);
     const size_t esz = (elem_kind == ADLHIP_ELEM_U32 || elem_kind == ADLHIP_ELEM_SOA32) ? 4 : 8;   // SoA: per array
     if (tmp_bytes) *tmp_bytes = align_up(n * esz, 256);
     if (work_bytes) *work_bytes = sort_work_bytes(d, elem_kind, n, sort_bits, level);

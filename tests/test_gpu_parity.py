@@ -1609,10 +1609,36 @@ def test_scratch_levels_and_graceful_degradation(dev):
         dev.toggleProfiling(False)
         dev.setParam("sort.msd2", 1)
         data.release(); tmp.release()
+    # level 2, lean: whole keys keep the large sort with 12 % of head-room in the first slabs -- 64 Mi u32 keys within 330 MB
+    n = 1 << 26
+    keys = oracle.keys_u32(n, seed=9)
+    _, lean = sizes(0, n, 32, 2)
+    _, full = sizes(0, n, 32, 1)
+    assert sizes(0, n, 32, 0)[1] < lean <= 330 * 1000 * 1000 < full, (lean, full)
+    assert sizes(2, 1 << 24, 64, 0)[1] < sizes(2, 1 << 24, 64, 2)[1] < sizes(2, 1 << 24, 64, 1)[1]
+    data, tmp, work = Buffer(dev, n, np.uint32), Buffer(dev, n, np.uint32), Buffer(dev, lean, np.uint8)
+    try:
+        dev.setParam("sort.msd2", 2)
+        # uniform keys: the large sort, no safety net; keys with a 30 % denser lower half: the net (correct all the same)
+        skew = np.where(np.arange(n) % 10 < 3, keys >> np.uint32(1), keys).astype(np.uint32)
+        for name, k, net in (("uniform", keys, False), ("denser lower half", skew, True)):
+            data.write(k)
+            dev.toggleProfiling(True); dev.profile(reset=True)
+            check(lib.adlhip_radix_sort_u32(dev._h, data.ptr(), tmp.ptr(), work.ptr(), lean, n, 32), "sort")
+            prof = dev.profile(reset=True); dev.toggleProfiling(False)
+            assert set(prof) == LARGE_U32, (name, prof)
+            assert (prof["msd2_offsets"][1] > 1.0) == net, (name, prof["msd2_offsets"])
+            got = data.toHost()
+            assert np.array_equal(got, np.sort(k)), name
+        dev.checkFault()
+    finally:
+        dev.toggleProfiling(False)
+        dev.setParam("sort.msd2", 1)
+        data.release(); tmp.release(); work.release()
     rng = np.random.default_rng(6)
     sz = sorted(set([1 << k for k in range(12, 29)] + [(16 << 20) - 1, 16 << 20, (96 << 20) + 1] + [int(x) for x in rng.integers(1 << 12, 3 << 27, 120)]))
-    for kind, bits in ((0, 28), (0, 16), (1, 24), (2, 44), (3, 20)):
-        for level in (0, 1):
+    for kind, bits in ((0, 28), (0, 16), (1, 24), (2, 44), (3, 20), (0, 32), (2, 64)):
+        for level in (0, 1, 2):
             last = 0
             for nn in sz:
                 w = sizes(kind, nn, bits, level)[1]
