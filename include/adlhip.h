@@ -304,7 +304,7 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      device and sorted by a cooperative LSD sort inside the same launches (correct, slower);
  *                      the handle then steers later sorts by asynchronous hints (speed only; results never
  *                      depend on them).  2 / 3 force the two- / three-launch form (tests)
- *   "sort.msd2"        1 [default] / 0: sorts of 2 Mi .. 280 Mi u32 keys, 2 Mi .. 260 Mi u64 keys and 1 Mi .. 260 Mi pairs on 16 or
+ *   "sort.msd2"        1 [default] / 0: sorts of 2 Mi .. 1088 Mi u32 keys, 2 Mi .. 260 Mi u64 keys and 1 Mi .. 260 Mi pairs on 16 or
  *                      more bits take two MSD passes into slabs of the work buffer plus one finish in LDS (six moves of
  *                      every element instead of nine); where the two digits sit is chosen on the device from a sample of
  *                      the keys (inside the low sort_bits bits).  Whole keys: runs are placed with atomic cursors (equal keys

@@ -748,6 +748,20 @@ int launch_bin_segment_sort(adlhip_device* d, const S* in, E* out, const uint32_
     });
 }
 
+// the workgroup-per-segment finish of the large sort beyond 280 Mi u32 keys (hybrid_kernels.hpp wg_segment_sort_kernel)
+template <typename E, typename S, int NT, int K>
+int launch_wg_segment_sort(adlhip_device* d, const S* in, E* out, const uint32_t* seg_off, const uint32_t* seg_cnt, uint32_t in_stride,
+                           const uint32_t* mode, size_t slots)
+{
+    auto kern = adlhip::wg_segment_sort_kernel<E, S, NT, K>;
+    const size_t lds = sizeof(S) * NT * K + (size_t)(NT / 64) * 256 * 6;
+    if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
+    return launch(d, "segment_sort_wg_u32", [&] {
+        hipLaunchKernelGGL(kern, dim3((uint32_t)slots), dim3(NT), lds, d->stream, in, out, seg_off, seg_cnt, in_stride, mode,
+                           mode + adlhip::kDynLowBits, d->d_fault);
+    });
+}
+
 // largest segment the finishing kernel takes for this element size and number of low bits
 size_t segment_capacity(size_t elem_bytes, int low_bits)
 {
@@ -935,7 +949,9 @@ int mid_sort_keys(adlhip_device* d, uint32_t* data, uint32_t* tmp, void* work, s
 constexpr size_t kMsd2Min = kSmallMax;                             // elements; the path works from here ("sort.msd2" >= 2) ...
 constexpr size_t kMsd2AutoMin = size_t(2) << 20;                   // ... and is chosen above the mid-size sort's range
                                                                    // (profiles/r2_msd2_size_curve.txt: 2.5 Mi keys 58 vs 70 us)
-constexpr size_t kMsd2MaxU32 = size_t(280) << 20;                  // mean segment n / 65536 = 4480, + 7.5 sd <= 5120
+// up to 280 Mi keys a segment (mean n / 65536 = 4480, + 7.5 sd <= 5120) fits the 80 rows one wave holds; beyond, the finish takes one
+// workgroup per segment (wg_segment_sort_kernel: tiles of 8192 ... 20480 keys) up to a mean of 17408 + 7.5 sd
+constexpr size_t kMsd2MaxU32 = size_t(1088) << 20;
 constexpr size_t kMsd2MaxU64 = (size_t(1) << 28) + (size_t(1) << 22);   // mean segment 4160
 // the wave-per-segment finish's tiles: 64 * 20, 64 * 40, 64 * 80 elements
 
@@ -958,7 +974,8 @@ struct Msd2Layout {
 // density varied by 20 % over the key range already went to the safety net; 1536 takes ~45 % and costs nothing measurable
 // (finish 118.0 vs 118.3 us at 64 Mi keys: five workgroups of four waves per CU instead of three of eight)
 constexpr uint32_t kMsd2Stride0 = 1536;
-// tile of the finish for n elements: 1280 / 1536 / 2560 / 5120 (what a wave -- or a workgroup of the binning finish -- holds)
+// tile of the finish for n elements: 1280 / 1536 / 2560 / 5120 (what a wave -- or a workgroup of the binning finish -- holds),
+// 8192 ... 20480 for the workgroup-per-segment finish
 uint32_t msd2_tier_b(size_t n, uint32_t slots = 65536)
 {
     const size_t mean = (n + slots - 1) / slots;
@@ -966,7 +983,9 @@ uint32_t msd2_tier_b(size_t n, uint32_t slots = 65536)
     while (sd * sd < mean) ++sd;
     const size_t need = mean + (15 * sd + 1) / 2;
     // (the tiers' bounds on the mean stay as they were; up to a mean of ~640 the 1280-element tile already leaves 1.5 x)
-    return need <= 832 ? 1280u : need <= 1280 ? kMsd2Stride0 : need <= 2560 ? 2560u : 5120u;
+    if (need <= 5120) return need <= 832 ? 1280u : need <= 1280 ? kMsd2Stride0 : need <= 2560 ? 2560u : 5120u;
+    // (u32 keys beyond 280 Mi only: the workgroup-per-segment finish, 512 threads x 16 / 24 rows, 1024 x 16 / 20)
+    return need <= 8192 ? 8192u : need <= 12288 ? 12288u : need <= 16384 ? 16384u : 20480u;
 }
 // elements between two segment slabs: the mean + 50 % (or + 7.5 sd where that is more), at most the finish's tile.  (Round 2 spaced
 // the slabs by the tile whatever n was: 168 MB of second slab for 2 Mi keys.)
@@ -1330,6 +1349,36 @@ int launch_large_finish(adlhip_device* d, const E* slab_b, E* out, uint32_t* out
     // 256 << seg_shift slots (hybrid_kernels.hpp slot_to_segment)
     const uint32_t* lowb = mode + adlhip::kDynLowBits;
     const size_t slots = (size_t)256 << seg_shift;
+    // segments beyond a wave's tile: whole u32 keys above 280 Mi keys (16-bit second slab, 65536 segments).  The 5120-key tier
+    // (about 140 Mi ... 288 Mi keys) goes the same way: four waves with 20 rows per thread beat the one wave that holds 80
+    // (256 Mi keys: finish 0.64 -> 0.48 ms, 144 Mi: 0.80 -> 0.35); below, the wave per segment stays ahead (64 Mi keys: 0.125 vs
+    // 0.129 ms, 128 Mi: 0.218 vs 0.235).  Workgroup sizes by measurement (profiles/r3_wg_finish.txt): 5120 keys 256 x 20 | 512 x 10
+    // = 0.478 | 0.606 ms at 256 Mi keys; 8192: 256 x 32 | 512 x 16 = 0.672 | 0.731 at 384 Mi; 12288: 512 x 24 | 256 x 48 = 1.047 |
+    // 1.089 at 512 Mi; 16384 keys with 1024 x 16 took 2.37 ms against 1.63 with 512 x 32 at 768 Mi
+    constexpr bool wg_kind = !SOA && sizeof(E) == 4 && sizeof(S) == 2;
+    // A/B knobs: ADLHIP_WG_MIN_TIER = smallest tile that takes the workgroup finish, ADLHIP_WG_NT = 0 (default choice) / 128 / 256 / 512
+    static const uint32_t wg_min = getenv("ADLHIP_WG_MIN_TIER") ? (uint32_t)atoi(getenv("ADLHIP_WG_MIN_TIER")) : 5120u;
+    static const int wg_nt = getenv("ADLHIP_WG_NT") ? atoi(getenv("ADLHIP_WG_NT")) : 0;
+    if (tier_b > 5120 || (wg_kind && tier_b >= wg_min && seg_shift == 8)) {
+        if constexpr (wg_kind) {
+            const S* sb = reinterpret_cast<const S*>(slab_b);
+            if (seg_shift != 8) return fail("internal: the workgroup-per-segment finish takes 65536 segments");
+#define ADLHIP_WG(NT_, K_) return launch_wg_segment_sort<E, S, NT_, K_>(d, sb, out, seg_off, seg_cnt, stride_b, mode, slots)
+            switch (tier_b) {
+            case 1280: if (wg_nt == 256) ADLHIP_WG(256, 5); ADLHIP_WG(128, 10);
+            case 1536: if (wg_nt == 256) ADLHIP_WG(256, 6); ADLHIP_WG(128, 12);
+            case 2560: if (wg_nt == 128) ADLHIP_WG(128, 20); ADLHIP_WG(256, 10);
+            case 5120: if (wg_nt == 512) ADLHIP_WG(512, 10); ADLHIP_WG(256, 20);
+            case 8192: if (wg_nt == 512) ADLHIP_WG(512, 16); ADLHIP_WG(256, 32);
+            case 12288: if (wg_nt == 256) ADLHIP_WG(256, 48); ADLHIP_WG(512, 24);
+            case 16384: ADLHIP_WG(512, 32);
+            default: ADLHIP_WG(512, 40);
+            }
+#undef ADLHIP_WG
+        } else {
+            return fail("internal: no finish for segments of %u elements of this kind", tier_b);
+        }
+    }
     if constexpr (!SOA) {
         if (bin) {
             const S* sb = reinterpret_cast<const S*>(slab_b);

@@ -1,5 +1,5 @@
 // hybrid_kernels.hpp -- MSD passes + LDS-resident finish: the segment sort primitive (adlhip_segment_sort), the mid-size
-// sort (16 Ki .. 2 Mi keys) and the large sort (2 Mi .. 280 Mi keys, u64 keys, pairs) built on it.
+// sort (16 Ki .. 2 Mi keys) and the large sort (2 Mi .. 1088 Mi keys, u64 keys, pairs) built on it.
 //
 // The LSD sort of Pprims::radixSort (Tahoe/ParallelPrimitives/Pprims.cpp:304-406) moves every element through
 // global memory once per digit and costs one to three dependent kernel launches per digit.  Between 16 Ki and
@@ -584,6 +584,106 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
             wave_sort_dispatch<E, RMIN, K, STEP, true, S, false>((int)((m + 63u) >> 6), src, out + begin, nullptr, m, lane, buf, cnt,
                                                                  low_bits, hi);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Finish for segments beyond a wave's tile: the large sort of more than 280 Mi u32 keys leaves 65536 segments of 4.5 K ... 17 K
+// 16-bit keys each -- too many for the 80 rows one wave holds, so ONE WORKGROUP of NT threads takes a segment slab: load (S =
+// what the second slab holds) | per 8-bit local pass: returning DS atomics on the wave's own counters give the in-wave rank,
+// barrier, every wave folds all waves' counts for its lanes' bins and writes its own (wave, bin) positions, scatter into LDS,
+// barrier, read back | store with the bits above put back (`hi`, as in wave_segment_sort_kernel).  The body is
+// segment_sort_kernel's in-LDS branch; slots beyond the segment's size take no part.  Gated by the mode word like every finish.
+// ------------------------------------------------------------------------------------------
+template <typename E, typename S, int NT, int K>
+__global__ __launch_bounds__(NT) void wg_segment_sort_kernel(const S* __restrict__ in, E* __restrict__ out,
+                                                             const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_cnt,
+                                                             uint32_t in_stride, const uint32_t* __restrict__ gate,
+                                                             const uint32_t* __restrict__ dyn_low_bits, uint32_t* fault)
+{
+    if (*gate != 0u) return;
+    constexpr int NW = NT / 64;
+    constexpr int CAP = NT * K;
+    constexpr int BINS = 256;
+    constexpr int BPL = 4;
+    static_assert(CAP <= 65536, "16-bit tile positions");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    S* __restrict__ s_elems = reinterpret_cast<S*>(smem);   // the tile holds what the slab holds (16-bit keys: half the LDS, twice the workgroups)
+    uint32_t* __restrict__ s_wcnt = reinterpret_cast<uint32_t*>(smem + sizeof(S) * CAP);   // [NW][BINS]
+    uint16_t* __restrict__ s_wpos = reinterpret_cast<uint16_t*>(s_wcnt + NW * BINS);        // [NW][BINS]
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    uint32_t* my_wcnt = s_wcnt + w * BINS;
+    uint16_t* my_wpos = s_wpos + w * BINS;
+    const uint32_t seg = blockIdx.x;
+    const uint32_t m = seg_cnt[seg];
+    if (m == 0u) return;
+    const uint32_t low_bits = dyn_low_bits[0];
+    if (m > (uint32_t)CAP || low_bits > 8u * (uint32_t)sizeof(S)) {   // never sort wrongly in silence
+        if (tid == 0) atomicOr(fault + 1, 0x40000u);
+        return;
+    }
+    const S* __restrict__ src = in + (size_t)seg * in_stride;
+    E* __restrict__ dst = out + seg_off[seg];
+    const E hi = sizeof(S) < sizeof(E) ? (E)(((dyn_low_bits[1] << 16) | seg) << low_bits) : E(0);
+    const int npass = ((int)low_bits + 7) / 8;
+    // wave-striped: with keff = ceil(m / NT) items per thread in use, wave w owns elements [w*64*keff, (w+1)*64*keff)
+    const int keff = (int)((m + (uint32_t)NT - 1u) / (uint32_t)NT);
+    const uint32_t wbase = (uint32_t)(w * 64 * keff + lane);
+    const int rem = (int)m - (int)wbase;   // item j of this lane exists iff j*64 < rem
+    E e[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (j < keff) e[j] = (j * 64 < rem) ? (E)src[wbase + (uint32_t)(j * 64)] : E(0);
+    int sb = 0;
+    for (int p = 0; p < npass; ++p) {
+        const int nb = ((int)low_bits - sb + (npass - p - 1)) / (npass - p);
+        const uint32_t mask = (1u << nb) - 1u;
+        auto digit = [&](E x) -> uint32_t { return (uint32_t)(x >> sb) & mask; };
+#pragma unroll
+        for (int q = 0; q < BPL; ++q) my_wcnt[q * 64 + lane] = 0u;
+        // the in-wave rank (< 64 K <= 4096) rides in the upper half of the element's register: the keys are 16 bits wide, and a
+        // second array of K registers costs a workgroup per CU at the large tiles (157 VGPRs at 40 rows)
+        static_assert(sizeof(S) == 2 && sizeof(E) == 4 && 64 * K <= 65536, "16-bit keys in 32-bit registers");
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j < keff && j * 64 < rem)
+                e[j] |= __hip_atomic_fetch_add(&my_wcnt[digit(e[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) << 16;
+        __syncthreads();   // every wave's counts are final; the previous pass's read-back is done
+        {   // lane l owns bins [4l, 4l + 4): totals over all waves, the part of the waves before mine, tile positions
+            u32x4 tot = {0u, 0u, 0u, 0u}, pre = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const u32x4 r = *reinterpret_cast<const u32x4*>(s_wcnt + i * BINS + lane * BPL);
+                tot += r;
+                if (i < w) pre += r;
+            }
+            const uint32_t s4 = tot.x + tot.y + tot.z + tot.w;
+            const uint32_t run = wave_incl_scan_u32(s4) - s4;
+            const uint32_t p0 = run + pre.x, p1 = run + tot.x + pre.y, p2 = run + tot.x + tot.y + pre.z,
+                           p3 = run + tot.x + tot.y + tot.z + pre.w;
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 packed = {p0 | (p1 << 16), p2 | (p3 << 16)};   // positions < CAP <= 65536
+            *reinterpret_cast<u32x2*>(my_wpos + lane * BPL) = packed;
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j < keff && j * 64 < rem) s_elems[(uint32_t)my_wpos[digit(e[j])] + (e[j] >> 16)] = (S)e[j];
+        __syncthreads();   // the tile is in sorted order
+        if (p + 1 < npass) {
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if (j < keff && j * 64 < rem) e[j] = (E)s_elems[wbase + (uint32_t)(j * 64)];
+        }
+        sb += nb;
+    }
+    if (npass == 0) {   // nothing left to sort: the segment only moves
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j < keff && j * 64 < rem) dst[wbase + (uint32_t)(j * 64)] = e[j] | hi;
+    } else {
+        for (uint32_t i = (uint32_t)tid; i < m; i += (uint32_t)NT) dst[i] = (E)s_elems[i] | hi;
     }
 }
 
@@ -1255,7 +1355,7 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
 }
 
 // ------------------------------------------------------------------------------------------
-// Large keys-only sort ("sort.msd2", 2 Mi < n <= 280 Mi u32 keys, u64 keys likewise): TWO unstable MSD passes with bucket
+// Large keys-only sort ("sort.msd2", 2 Mi < n <= 1088 Mi u32 keys, u64 keys up to 260 Mi): TWO unstable MSD passes with bucket
 // cursors (first digit, then second digit inside every bucket: 65536 segments of n / 65536 keys; where the digits sit is chosen
 // from a sample of the keys, msd2_placement) and ONE LDS finish (wave_segment_sort_kernel on the bits below).  No histogram
 // kernel, no look-back, every key moved 6 times instead of 9 (u32 keys: the second slab holds their low 16 bits only).  msd2_offsets_kernel sits between the

@@ -435,29 +435,69 @@ def test_soa_64m_pairs(dev, pp):
     assert np.array_equal(gv, (want >> np.uint64(32)).astype(np.uint32))
 
 
-def test_u32_2p30_plus_12345_three_kernel_path(dev, pp):
-    """n >= 2^30: the automatic choice must leave the one-sweep path (status words carry 30-bit counts); 4 GiB of keys,
-    element indices close to the 32-bit limit of the kernels.  Bit-exact against the oracle."""
+def test_u32_2p30_plus_12345_three_kernel_path_and_large_sort(dev, pp):
+    """n >= 2^30: the per-digit choice must leave the one-sweep path (status words carry 30-bit counts); 4 GiB of keys,
+    element indices close to the 32-bit limit of the kernels.  And the large sort at this size: segments of 16 Ki 16-bit keys,
+    finished by one workgroup each (wg_segment_sort_kernel, 20480-key tile).  Both bit-exact against the oracle."""
     n = (1 << 30) + 12345
     keys = oracle.keys_u32(n, seed=99)
-    b = Buffer(dev, n, np.uint32)
-    b.write(keys)
-    dev.toggleProfiling(True)
-    dev.profile(reset=True)
-    pp.radixSort(dev, b, n)
-    prof = dev.profile(reset=True)
-    dev.toggleProfiling(False)
-    assert any(k.startswith("scatter_u32") for k in prof) and not any(k.startswith("onesweep") for k in prof), prof
     want = oracle.sort_u32(keys)
-    del keys
+    b = Buffer(dev, n, np.uint32)
     CH = 1 << 27
     chunk = np.empty(CH, dtype=np.uint32)
-    for off in range(0, n, CH):
-        m = min(CH, n - off)
-        b.read(chunk[:m], m, off)
-        DeviceUtils.waitForCompletion(dev)
-        assert np.array_equal(chunk[:m], want[off:off + m]), off
-    b.release()
+    set_algo(dev, (-1, 8, -1))
+    try:
+        for msd2 in (0, 4):
+            dev.setParam("sort.msd2", msd2)
+            b.write(keys)
+            dev.toggleProfiling(True)
+            dev.profile(reset=True)
+            pp.radixSort(dev, b, n)
+            prof = dev.profile(reset=True)
+            dev.toggleProfiling(False)
+            if msd2 == 0:
+                assert any(k.startswith("scatter_u32") for k in prof) and not any(k.startswith("onesweep") for k in prof), prof
+            else:
+                assert set(prof) == {"msd2_sample", "msd2_pass1_u32", "msd2_pass2_u32", "msd2_offsets", "segment_sort_wg_u32"}, prof
+            for off in range(0, n, CH):
+                m = min(CH, n - off)
+                b.read(chunk[:m], m, off)
+                DeviceUtils.waitForCompletion(dev)
+                assert np.array_equal(chunk[:m], want[off:off + m]), (msd2, off)
+        dev.checkFault()
+    finally:
+        dev.toggleProfiling(False)
+        dev.setParam("sort.msd2", 1)
+        b.release()
+
+
+@pytest.mark.parametrize("n", [(300 << 20) + 77, (1 << 29) + 4321, (896 << 20) + 5], ids=["300Mi+77", "512Mi+4321", "896Mi+5"])
+def test_large_sort_beyond_280mi_u32_keys(dev, pp, n):
+    """Above 280 Mi u32 keys a segment of the large sort no longer fits the 80 rows one wave holds; the finish then takes one
+    workgroup per segment (tiles of 8192 / 12288 / 16384 / 20480 16-bit keys: these sizes and the 2^30 test take one each).
+    Uniform keys, keys that use one eighth of the range (digits placed from the sample) and, at the smallest size, keys that
+    overflow a bucket (safety net).  Bit-exact against the oracle."""
+    set_algo(dev, (-1, 8, -1))
+    dev.setParam("sort.msd2", 4)
+    names = {"msd2_sample", "msd2_pass1_u32", "msd2_pass2_u32", "msd2_offsets", "segment_sort_wg_u32"}
+    try:
+        keys = oracle.keys_u32(n, seed=n & 0xfff)
+        got, prof = _profiled(dev, lambda: gpu_sort_u32(dev, pp, keys))
+        assert set(prof) == names, prof
+        assert prof["msd2_offsets"][1] < 1.0, prof   # no safety net
+        assert np.array_equal(got, oracle.sort_u32(keys))
+        if n < (1 << 29):
+            eighth = (keys >> np.uint32(3)) | np.uint32(0xa0000000)
+            got, prof = _profiled(dev, lambda: gpu_sort_u32(dev, pp, eighth))
+            assert set(prof) == names and prof["msd2_offsets"][1] < 1.0, prof
+            assert np.array_equal(got, oracle.sort_u32(eighth))
+            skew = np.where(np.arange(n) % 4 == 0, keys >> np.uint32(8), keys).astype(np.uint32)   # a quarter of the keys in one bucket
+            got, prof = _profiled(dev, lambda: gpu_sort_u32(dev, pp, skew))
+            assert prof["msd2_offsets"][1] > 1.0, prof   # the safety net sorted
+            assert np.array_equal(got, oracle.sort_u32(skew))
+        dev.checkFault()
+    finally:
+        dev.setParam("sort.msd2", 1)
 
 
 def test_stopwatch_and_profiling(dev, pp):
@@ -743,7 +783,7 @@ def test_abi_argument_validation(dev):
     assert b"work buffer too small" in lib.adlhip_last_error()
     assert ok(lib.adlhip_radix_sort_u32(dev._h, keys.ptr(), tmp.ptr(), work.ptr(), wb.value - 1, n, 32))
     assert not ok(lib.adlhip_radix_sort_scratch_bytes_for(dev._h, 0, n, 30, 1, ctypes.byref(t0), ctypes.byref(w0)))   # not a multiple of 4
-    assert not ok(lib.adlhip_radix_sort_scratch_bytes_for(dev._h, 0, n, 32, 2, ctypes.byref(t0), ctypes.byref(w0)))   # no such level
+    assert not ok(lib.adlhip_radix_sort_scratch_bytes_for(dev._h, 0, n, 32, 3, ctypes.byref(t0), ctypes.byref(w0)))   # no such level
     # null buffers
     assert not ok(lib.adlhip_radix_sort_u32(dev._h, keys.ptr(), None, work.ptr(), wb.value, n, 32))
     assert not ok(lib.adlhip_radix_sort_u32(dev._h, None, tmp.ptr(), work.ptr(), wb.value, n, 32))
