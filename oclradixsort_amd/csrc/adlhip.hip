@@ -976,12 +976,15 @@ struct Msd2Layout {
 constexpr uint32_t kMsd2Stride0 = 1536;
 // tile of the finish for n elements: 1280 / 1536 / 2560 / 5120 (what a wave -- or a workgroup of the binning finish -- holds),
 // 8192 ... 20480 for the workgroup-per-segment finish
-uint32_t msd2_tier_b(size_t n, uint32_t slots = 65536)
+// fine: whole u32 keys with a 16-bit second slab -- from 2560 keys up their finish is the workgroup kernel, which has tiles of 3072
+// and 4096 keys too (a half-empty 5120-key tile costs its 20 predicated rows all the same: 144 Mi keys 0.35 ms for the finish)
+uint32_t msd2_tier_b(size_t n, uint32_t slots = 65536, bool fine = false)
 {
     const size_t mean = (n + slots - 1) / slots;
     size_t sd = 1;
     while (sd * sd < mean) ++sd;
     const size_t need = mean + (15 * sd + 1) / 2;
+    if (fine && need > 2560 && need <= 4096) return need <= 3072 ? 3072u : 4096u;
     // (the tiers' bounds on the mean stay as they were; up to a mean of ~640 the 1280-element tile already leaves 1.5 x)
     if (need <= 5120) return need <= 832 ? 1280u : need <= 1280 ? kMsd2Stride0 : need <= 2560 ? 2560u : 5120u;
     // (u32 keys beyond 280 Mi only: the workgroup-per-segment finish, 512 threads x 16 / 24 rows, 1024 x 16 / 20)
@@ -989,13 +992,13 @@ uint32_t msd2_tier_b(size_t n, uint32_t slots = 65536)
 }
 // elements between two segment slabs: the mean + 50 % (or + 7.5 sd where that is more), at most the finish's tile.  (Round 2 spaced
 // the slabs by the tile whatever n was: 168 MB of second slab for 2 Mi keys.)
-uint32_t msd2_stride_b(size_t n, uint32_t slots = 65536)
+uint32_t msd2_stride_b(size_t n, uint32_t slots = 65536, bool fine = false)
 {
     const size_t mean = (n + slots - 1) / slots;
     size_t sd = 1;
     while (sd * sd < mean) ++sd;
     const size_t want = align_up(std::max(mean + mean / 2, mean + (15 * sd + 1) / 2) + 8, 64);
-    return (uint32_t)std::min<size_t>(want, msd2_tier_b(n, slots));
+    return (uint32_t)std::min<size_t>(want, msd2_tier_b(n, slots, fine));
 }
 
 // Width w of the second digit of the cursor form (hybrid_kernels.hpp slot_to_segment): 8 from 12 Mi elements up; below, as many
@@ -1033,8 +1036,9 @@ Msd2Layout msd2_layout(size_t n, size_t elem_bytes, int headroom_pct = kFullHead
     L.stride_a = (uint32_t)align_up(n / 256 + (n / 256) * (size_t)headroom_pct / 100 + 4096, 64);
     L.seg_shift = msd2_seg_shift(n, elem_bytes == 8);   // the cursor form sorts whole keys: 8-byte elements = u64 keys
     L.slots = 256u << L.seg_shift;
-    L.stride_b = msd2_stride_b(n, L.slots);
-    L.tier_b = msd2_tier_b(n, L.slots);
+    const bool fine = elem_bytes == 4 && L.seg_shift == 8;   // whole u32 keys, 16-bit second slab
+    L.stride_b = msd2_stride_b(n, L.slots, fine);
+    L.tier_b = msd2_tier_b(n, L.slots, fine);
     L.tiles_per_bucket = (L.stride_a + tile - 1) / tile;
     L.off_mode = 0;
     L.off_cnt = L.off_mode + 256;
@@ -1277,8 +1281,8 @@ Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8, bool slab16 = false)
     // (whole u32 keys keep 65536 segments: their second slab holds 16-bit keys only while the finish has 16 bits to sort)
     L.seg_shift = slab16 ? 8u : msd2_seg_shift(n, false);
     L.slots = 256u << L.seg_shift;
-    L.stride_b = msd2_stride_b(n, L.slots);
-    L.tier_b = msd2_tier_b(n, L.slots);
+    L.stride_b = msd2_stride_b(n, L.slots, slab16);
+    L.tier_b = msd2_tier_b(n, L.slots, slab16);
     L.ticket_words = (32 + 256) * adlhip::kTicketStride;
     L.status_bytes_a = (size_t)L.pieces * L.rows_a * 1024;
     L.status_bytes_b = (size_t)256 * L.rows_b * 1024;
@@ -1357,7 +1361,7 @@ int launch_large_finish(adlhip_device* d, const E* slab_b, E* out, uint32_t* out
     // 1.089 at 512 Mi; 16384 keys with 1024 x 16 took 2.37 ms against 1.63 with 512 x 32 at 768 Mi
     constexpr bool wg_kind = !SOA && sizeof(E) == 4 && sizeof(S) == 2;
     // A/B knobs: ADLHIP_WG_MIN_TIER = smallest tile that takes the workgroup finish, ADLHIP_WG_NT = 0 (default choice) / 128 / 256 / 512
-    static const uint32_t wg_min = getenv("ADLHIP_WG_MIN_TIER") ? (uint32_t)atoi(getenv("ADLHIP_WG_MIN_TIER")) : 5120u;
+    static const uint32_t wg_min = getenv("ADLHIP_WG_MIN_TIER") ? (uint32_t)atoi(getenv("ADLHIP_WG_MIN_TIER")) : 3072u;
     static const int wg_nt = getenv("ADLHIP_WG_NT") ? atoi(getenv("ADLHIP_WG_NT")) : 0;
     if (tier_b > 5120 || (wg_kind && tier_b >= wg_min && seg_shift == 8)) {
         if constexpr (wg_kind) {
@@ -1368,6 +1372,8 @@ int launch_large_finish(adlhip_device* d, const E* slab_b, E* out, uint32_t* out
             case 1280: if (wg_nt == 256) ADLHIP_WG(256, 5); ADLHIP_WG(128, 10);
             case 1536: if (wg_nt == 256) ADLHIP_WG(256, 6); ADLHIP_WG(128, 12);
             case 2560: if (wg_nt == 128) ADLHIP_WG(128, 20); ADLHIP_WG(256, 10);
+            case 3072: ADLHIP_WG(256, 12);
+            case 4096: ADLHIP_WG(256, 16);
             case 5120: if (wg_nt == 512) ADLHIP_WG(512, 10); ADLHIP_WG(256, 20);
             case 8192: if (wg_nt == 512) ADLHIP_WG(512, 16); ADLHIP_WG(256, 32);
             case 12288: if (wg_nt == 256) ADLHIP_WG(256, 48); ADLHIP_WG(512, 24);
