@@ -820,11 +820,19 @@ MidLayout mid_layout(size_t n)
     return L;
 }
 
+// u32 keys take the two-launch mid-size sort from here -- below the one-workgroup sort's limit kSmallMax: 10000 keys 16.5 -> 15.6 us,
+// 12288 17.9 -> 15.5, 16384 19.3 -> 15.4; from 4096 it loses (6000 keys 13.6 -> 15.1).  profiles/r3_small_mid_ab.txt; A/B: ADLHIP_MID_MIN
+size_t mid_min_u32()
+{
+    static const size_t v = getenv("ADLHIP_MID_MIN") ? (size_t)atoll(getenv("ADLHIP_MID_MIN")) : 8192;
+    return v;
+}
+
 bool mid_eligible(const adlhip_device* d, size_t elem_bytes, size_t n, int sort_bits, int max_bits)
 {
     if (d->resident_wgs < 256) return false;   // the finish's one workgroup per bucket doubles as a 256-workgroup cooperative sort
     return d->sort_algo < 0 && d->mid_path && max_bits == 32 && sort_bits == 32 && d->rank_mode == 1 && d->digit_bits == 8 &&
-           d->tile_variant < 0 && n > kSmallMax && n <= (elem_bytes == 4 ? kMidMaxU32 : kMidMaxE64);
+           d->tile_variant < 0 && n > (elem_bytes == 4 ? mid_min_u32() : kSmallMax) && n <= (elem_bytes == 4 ? kMidMaxU32 : kMidMaxE64);
 }
 
 // Which form an eligible sort takes: 2 = two launches (u32 keys only), 3 = three launches, 0 = the per-digit passes.
@@ -1638,14 +1646,20 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
         fprintf(stderr, "[adlhip] sort kind %d n %zu bits %d data %p tmp %p work %p + %zu\n", elem_kind, n, sort_bits, (void*)data, (void*)tmp,
                 work, work_bytes);
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
-    if (d->sort_algo < 0 && n <= kSmallMax) return small_sort<E>(d, data, n, plan);   // one workgroup, one launch
+    // one workgroup, one launch -- except u32 keys just below its limit, which the two-launch mid-size sort does faster (while
+    // the handle's hints do not keep them off it)
+    const bool small = d->sort_algo < 0 && n <= kSmallMax;
+    const bool small_mid = small && sizeof(E) == 4 && sort_bits == max_bits && n > mid_min_u32() && (d->mid_path == 2 || d->mid2_skip == 0);
+    if (small && !small_mid) return small_sort<E>(d, data, n, plan);
     if (mid_eligible(d, sizeof(E), n, sort_bits, max_bits) && mid_layout(n).total <= work_bytes) {
         const int form = choose_mid_form(d, sizeof(E) == 4);
         if constexpr (sizeof(E) == 4) {
             if (form == 2) return mid_sort_keys(d, data, tmp, work, n);   // two launches
         }
+        if (small) return small_sort<E>(d, data, n, plan);                // (a small input never takes the slower forms)
         if (form == 3) return mid_sort<E>(d, data, tmp, work, n);         // three launches
     }
+    if (small) return small_sort<E>(d, data, n, plan);
     const bool keys = (int)sizeof(E) * 8 == max_bits;
     LargeForm form = large_sort_form(d, sizeof(E), keys, n, sort_bits, max_bits);
     int headroom = kFullHeadroomPct;

@@ -1402,7 +1402,10 @@ def test_size_classes_run_the_kernels_they_claim(dev):
     p = Pprims()
     try:
         cases = [
-            (16000, {}, {"small_sort_u32"}),
+            (8000, {}, {"small_sort_u32"}),
+            (16000, {"sort.mid": 0}, {"small_sort_u32"}),
+            (16000, {"sort.mid": 2}, {"mid_bucket_scatter_u32", "segment_sort_u32"}),   # u32 keys above 8 Ki: the two-launch form is faster
+            (8193, {"sort.mid": 2}, {"mid_bucket_scatter_u32", "segment_sort_u32"}),
             (300007, {"sort.mid": 2}, {"mid_bucket_scatter_u32", "segment_sort_u32"}),
             (300007, {"sort.mid": 3}, {"mid_prep_u32", "onesweep_u32_8b", "segment_sort_u32"}),
             ((1 << 22) + 5, {"sort.msd2": 2}, LARGE_U32),
