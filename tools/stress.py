@@ -32,6 +32,7 @@ while time.time() < t_end and it < args.stop_after:
     n = int(2 ** rng.uniform(10, 25.5)) + int(rng.randint(0, 1000))
     if it % 7 == 0: n = int(2 ** rng.uniform(21, 26.3))   # more of the large sort's range
     if kind == "u32" and it % 23 == 0: n = (1 << 26) + int(rng.randint(1, 1 << 22))     # past 256 MiB: pointer stores
+    if kind == "u32" and it % 37 == 0: n = int(2 ** rng.uniform(27.1, 28.6))            # 140 Mi ... 400 Mi keys: segments finished by a workgroup each
     algo = int(rng.choice([0, 0, 1, -1, -1, -1])); bits = int(rng.choice([8, 8, 8, 4])); tile = int(rng.choice([-1, -1, 0, 1, 2, 5]))
     if algo < 0: bits, tile = 8, -1   # what the automatic paths run with
     d.setParam("sort.algo", algo); d.setParam("sort.digit_bits", bits); d.setParam("sort.tile", tile)
