@@ -471,10 +471,12 @@ def test_u32_2p30_plus_12345_three_kernel_path_and_large_sort(dev, pp):
         b.release()
 
 
-@pytest.mark.parametrize("n", [(300 << 20) + 77, (1 << 29) + 4321, (896 << 20) + 5], ids=["300Mi+77", "512Mi+4321", "896Mi+5"])
+@pytest.mark.parametrize("n", [(150 << 20) + 3, (200 << 20) + 1, (300 << 20) + 77, (1 << 29) + 4321, (896 << 20) + 5],
+                         ids=["150Mi+3", "200Mi+1", "300Mi+77", "512Mi+4321", "896Mi+5"])
 def test_large_sort_beyond_280mi_u32_keys(dev, pp, n):
     """Above 280 Mi u32 keys a segment of the large sort no longer fits the 80 rows one wave holds; the finish then takes one
-    workgroup per segment (tiles of 8192 / 12288 / 16384 / 20480 16-bit keys: these sizes and the 2^30 test take one each).
+    workgroup per segment (tiles of 8192 / 12288 / 16384 / 20480 16-bit keys: these sizes and the 2^30 test take one each).  The
+    same kernel serves the tiles of 3072 / 4096 / 5120 keys from about 140 Mi keys (150 Mi+3, 200 Mi+1; 256 Mi in another test).
     Uniform keys, keys that use one eighth of the range (digits placed from the sample) and, at the smallest size, keys that
     overflow a bucket (safety net).  Bit-exact against the oracle."""
     set_algo(dev, (-1, 8, -1))
