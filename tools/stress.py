@@ -16,11 +16,12 @@ from oclradixsort_amd import Buffer, DeviceUtils, Pprims, _lib
 from oclradixsort_amd._lib import check
 ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=60.0)
 ap.add_argument("--skip-before", type=int, default=0, help="replay: draw the first iterations without running them")
-ap.add_argument("--stop-after", type=int, default=1 << 30); ap.add_argument("--verbose", action="store_true"); args = ap.parse_args()
+ap.add_argument("--stop-after", type=int, default=1 << 30); ap.add_argument("--verbose", action="store_true")
+ap.add_argument("--seed", type=int, default=2026); args = ap.parse_args()
 skip_before, verbose = args.skip_before, args.verbose
 d = DeviceUtils.allocate(); p = Pprims()
 d2 = DeviceUtils.allocate(); selftests = 0
-rng = np.random.RandomState(2026)
+rng = np.random.RandomState(args.seed)
 t_end = time.time() + args.seconds
 it = 0; elems = 0; t_mark = time.time()
 def checks(a):
