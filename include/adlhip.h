@@ -297,7 +297,7 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      intrinsics only, ~1.6x the pass time.  Every LSD pass must be stable, so key-only
  *                      sorts depend on this as much as key-value sorts do.
  *   "sort.lds_ordered" (read-only) result of that self-test
- *   "sort.mid"         1 [default] / 0: between 16 Ki and 2 Mi keys (1 Mi pairs), full 32-bit sorts take two
+ *   "sort.mid"         1 [default] / 0: between 8 Ki and 2 Mi u32 keys (16 Ki and 1 Mi pairs), full 32-bit sorts take two
  *                      launches (u32 keys: MSD pass with bucket cursors, buckets finished in LDS) or three
  *                      (pairs; keys with a constant top byte: byte histograms, stable MSD pass, LDS finish)
  *                      instead of the per-digit passes.  Keys that do not fit the buckets are detected on the
