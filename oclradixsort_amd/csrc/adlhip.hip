@@ -22,6 +22,8 @@
 #include "onesweep_kernels.hpp"
 #include "hybrid_kernels.hpp"
 #include "dict_kernels.hpp"
+#include "persist_kernels.hpp"
+#include "finish16_kernels.hpp"
 
 namespace {
 
@@ -92,6 +94,7 @@ struct adlhip_device {
     int mid_backoff = 32, mid2_backoff = 64;
     int bin_finish = 1;       // "sort.binfinish": the large keys-only sort finishes its segments with one counting pass + compares
                               // (1: u64 keys, 2: u32 keys too, 0: the wave-per-segment LSD finish)
+    int persist = 1;          // "sort.persist": the cursor passes of the large sort as persistent, prefetching kernels + the 16-bit finish
     int msd2_path = 1;        // "sort.msd2": the large sort (msd2_sort for keys, msd2s_sort for pairs); 2 = forced (tests)
     int msd2_skip = 0, msd2_backoff = 32;   // sorts the next overflow report keeps off the large sort (x8 each time, reset by a success)
     bool msd2_trusted = false;              // a good report has come in since the last bad one (msd2_decide)
@@ -1206,7 +1209,21 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int headr
     pa.zero_me = nullptr; pa.sample = sample; pa.which_digit = 1; pa.dst16 = 0;
     pa.place = nullptr; pa.status_a = nullptr; pa.pieces = 0; pa.rows_per_chain_a = 0; pa.slice = 0; pa.seg_shift = 8;
     const uint32_t tiles_a = (uint32_t)((n + CT::TILE - 1) / CT::TILE);
-    rc = launch(d, k32 ? "msd2_pass1_u32" : "msd2_pass1_u64", [&] { hipLaunchKernelGGL(kern, dim3(tiles_a), dim3(512), CT::LDS_BYTES, d->stream, pa); });
+    // round 4: the same pass as a persistent kernel -- 2 workgroups per CU take the tiles in turns, the next tile's keys are in
+    // flight (non-temporal 16-byte buffer loads) while the current one is ranked, and no wait ever covers a tile's stores
+    // (persist_kernels.hpp).  Buffer addressing: the slabs must lie within 4 GiB of their base.
+    const bool slab16 = sizeof(E) == 4 && L.seg_shift == 8;
+    const bool persist = d->persist && (size_t)256 * L.stride_a * sizeof(E) < (size_t(1) << 32) - (1u << 20) &&
+                         (size_t)L.slots * L.stride_b * (slab16 ? 2 : sizeof(E)) < (size_t(1) << 32) - (1u << 20);
+    using PC = adlhip::PersistCfg<E, 512, K>;
+    const uint32_t pgrid = (uint32_t)(2 * d->prop.multiProcessorCount + 7) / 8 * 8;   // a multiple of 8: workgroup % 8 = XCD
+    if (persist) {
+        auto pk = adlhip::msd_scatter_persist_kernel<E, 512, K, 1, 4, false, 2, 0>;
+        if (ensure_lds(pk, PC::LDS_BYTES)) return ADLHIP_FAILURE;
+        rc = launch(d, k32 ? "msd2_pass1_u32" : "msd2_pass1_u64", [&] { hipLaunchKernelGGL(pk, dim3(pgrid), dim3(512), PC::LDS_BYTES, d->stream, pa); });
+    } else {
+        rc = launch(d, k32 ? "msd2_pass1_u32" : "msd2_pass1_u64", [&] { hipLaunchKernelGGL(kern, dim3(tiles_a), dim3(512), CT::LDS_BYTES, d->stream, pa); });
+    }
     if (rc) return rc;
     adlhip::BucketPass<E> pb = pa;   // pass 2: every bucket, second digit -> 65536 segment slabs
     pb.src = slab_a; pb.dst = slab_b; pb.cursors = cur_b; pb.cursor_shift = 0; pb.src_count_shift = 5; pb.flag = flag;
@@ -1214,11 +1231,20 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int headr
     pb.src_stride = L.stride_a; pb.tiles_per_bucket = L.tiles_per_bucket; pb.dst_stride = L.stride_b;
     pb.dst_total = L.slots * L.stride_b; pb.start_bit = KEY_BITS - 16; pb.zero_me = nullptr;
     pb.sample = sample; pb.which_digit = 2; pb.seg_shift = L.seg_shift;
-    const bool slab16 = sizeof(E) == 4 && L.seg_shift == 8;
     pb.dst16 = slab16 ? 1 : 0;   // u32 keys: the second slab holds the low 16 bits only
-    rc = launch(d, k32 ? "msd2_pass2_u32" : "msd2_pass2_u64", [&] {
-        hipLaunchKernelGGL(kern2, dim3(256 * L.tiles_per_bucket), dim3(512), CT::LDS_BYTES, d->stream, pb);
-    });
+    if (persist) {
+        auto pk16 = adlhip::msd_scatter_persist_kernel<E, 512, K, 2, 4, true, 2, 0>;
+        auto pkE = adlhip::msd_scatter_persist_kernel<E, 512, K, 2, 4, false, 2, 0>;
+        if (ensure_lds(pk16, PC::LDS_BYTES) || ensure_lds(pkE, PC::LDS_BYTES)) return ADLHIP_FAILURE;
+        rc = launch(d, k32 ? "msd2_pass2_u32" : "msd2_pass2_u64", [&] {
+            if (slab16) hipLaunchKernelGGL(pk16, dim3(pgrid), dim3(512), PC::LDS_BYTES, d->stream, pb);
+            else hipLaunchKernelGGL(pkE, dim3(pgrid), dim3(512), PC::LDS_BYTES, d->stream, pb);
+        });
+    } else {
+        rc = launch(d, k32 ? "msd2_pass2_u32" : "msd2_pass2_u64", [&] {
+            hipLaunchKernelGGL(kern2, dim3(256 * L.tiles_per_bucket), dim3(512), CT::LDS_BYTES, d->stream, pb);
+        });
+    }
     if (rc) return rc;
     // segment sizes and offsets -- and, when a run did not fit its slab, the safety net: the same 256 resident workgroups sort
     // the untouched input with the cooperative LSD sort (hybrid_kernels.hpp coop_lsd_sort); the finish then returns at once
@@ -1368,6 +1394,26 @@ int launch_large_finish(adlhip_device* d, const E* slab_b, E* out, uint32_t* out
     // = 0.478 | 0.606 ms at 256 Mi keys; 8192: 256 x 32 | 512 x 16 = 0.672 | 0.731 at 384 Mi; 12288: 512 x 24 | 256 x 48 = 1.047 |
     // 1.089 at 512 Mi; 16384 keys with 1024 x 16 took 2.37 ms against 1.63 with 512 x 32 at 768 Mi
     constexpr bool wg_kind = !SOA && sizeof(E) == 4 && sizeof(S) == 2;
+    // round 4: 16-bit keys stay 16 bits wide in the finish (finish16_kernels.hpp): tiles of 1280 / 1536 / 2560 keys, one wave each
+    if constexpr (wg_kind) {
+        if (d->persist && !bin && seg_shift == 8 && tier_b <= 2560 && (stride_b & 1u) == 0u) {
+            const uint16_t* sb = reinterpret_cast<const uint16_t*>(slab_b);
+#define ADLHIP_F16(R2_, WAVES_)                                                                                                      \
+    {                                                                                                                                \
+        auto kf = adlhip::wave_finish16_kernel<R2_, WAVES_, true>;                                                                   \
+        const size_t lds = (size_t)WAVES_ * adlhip::Finish16Cfg<R2_>::PER_WAVE;                                                      \
+        if (ensure_lds(kf, lds)) return ADLHIP_FAILURE;                                                                              \
+        return launch(d, "segment_sort_wave_u32", [&] {                                                                              \
+            hipLaunchKernelGGL(kf, dim3((uint32_t)((slots + WAVES_ - 1) / WAVES_)), dim3(64 * WAVES_), lds, d->stream, sb, out, seg_off,       \
+                               seg_cnt, stride_b, mode, lowb, (uint32_t)slots, d->d_fault);                                          \
+        });                                                                                                                          \
+    }
+            if (tier_b <= 1280) ADLHIP_F16(10, 4)
+            if (tier_b <= 1536) ADLHIP_F16(12, 4)
+            ADLHIP_F16(20, 4)
+#undef ADLHIP_F16
+        }
+    }
     // A/B knobs: ADLHIP_WG_MIN_TIER = smallest tile that takes the workgroup finish, ADLHIP_WG_NT = 0 (default choice) / 128 / 256 / 512
     static const uint32_t wg_min = getenv("ADLHIP_WG_MIN_TIER") ? (uint32_t)atoi(getenv("ADLHIP_WG_MIN_TIER")) : 3072u;
     static const int wg_nt = getenv("ADLHIP_WG_NT") ? atoi(getenv("ADLHIP_WG_NT")) : 0;
@@ -2403,6 +2449,9 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
             return fail("sort.msd2 must be 0 (off), 1 (on), 2 (always, whatever the hints say; forms by size), 3 (always the stable passes), "
                         "4 (always the cursor passes for whole keys) or 5 (always the hybrid form for whole keys)");
         d->msd2_path = value;
+    } else if (!strcmp(name, "sort.persist")) {
+        if (value != 0 && value != 1) return fail("sort.persist must be 0 (one tile per workgroup, round 3) or 1 (persistent prefetching passes + 16-bit finish)");
+        d->persist = value;
     } else if (!strcmp(name, "sort.dict")) {
         if (value != 0 && value != 1) return fail("sort.dict must be 0 (off) or 1 (counting sort for keys that take few distinct values)");
         d->dict_path = value;
@@ -2439,6 +2488,7 @@ int adlhip_get_param(adlhip_device* d, const char* name, int* value)
     else if (!strcmp(name, "sort.mid")) *value = d->mid_path;
     else if (!strcmp(name, "sort.msd2")) *value = d->msd2_path;
     else if (!strcmp(name, "sort.binfinish")) *value = d->bin_finish;
+    else if (!strcmp(name, "sort.persist")) *value = d->persist;
     else if (!strcmp(name, "sort.dict")) *value = d->dict_path;
     else if (!strcmp(name, "debug.resident_wgs")) *value = d->resident_wgs;
     else if (!strcmp(name, "sort.lds_ordered")) *value = d->lds_ordered;
