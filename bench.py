@@ -81,10 +81,11 @@ def cpu_baseline(n):
 
 
 # rocprofv3 kernel names of the launch kinds bench.py prices (csrc/adlhip.hip launch names -> substrings of the kernel's name)
+SETTLE_SORTS = 80   # ~35 ms of sorting before the warm-up steps (see main)
 PMC_KERNEL = {
-    "msd2_pass1_u32": "msd_bucket_scatter_kernel<unsigned int, 512, 32, 1>",
-    "msd2_pass2_u32": "msd_bucket_scatter_kernel<unsigned int, 512, 32, 2>",
-    "segment_sort_wave_u32": "wave_segment_sort_kernel<unsigned int",
+    "msd2_pass1_u32": "msd_scatter_persist_kernel<unsigned int, 512, 32, 1,",
+    "msd2_pass2_u32": "msd_scatter_persist_kernel<unsigned int, 512, 32, 2,",
+    "segment_sort_wave_u32": "wave_finish16_kernel<",
     "onesweep_u32_8b": "onesweep_chain_kernel",
 }
 
@@ -166,6 +167,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config #3 / #5 extras beside the metric")
+    ap.add_argument("--no-settle", action="store_true", help="skip the clock-settle sorts before the warm-up steps (A/B)")
     ap.add_argument("--no-pmc", action="store_true", help="do not start the two rocprofv3 --pmc child runs for roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -260,6 +262,19 @@ def main():
             b.generate(n, seed=123 + i)
             bufs.append(b)
         DeviceUtils.waitForCompletion(d)
+        # Clock settle (not a warm-up STEP: it sorts a buffer of its own, fresh random keys every time): the chip comes out of the
+        # set-up above at a low clock and takes ~10 ms of sustained load to reach the one it holds in steady state -- the LDS-bound
+        # finish of a sort runs 122 us for the first dozen sorts after an idle gap and 102 us from the thirtieth on
+        # (profiles/r4_clock_ramp.txt; the HBM-bound passes do not change).  W warm-up steps of 0.35 ms each end inside that ramp.
+        settle_sorts = 0 if args.no_settle else SETTLE_SORTS
+        sb = Buffer(d, n, np.uint32) if settle_sorts else None
+
+        def settle():
+            for i in range(settle_sorts):
+                sb.generate(n, seed=7000 + i)
+                p.radixSort(d, sb, n)
+
+        settle()
         for i in range(W):
             p.radixSort(d, bufs[i], n)
         DeviceUtils.waitForCompletion(d)
@@ -289,12 +304,15 @@ def main():
         for i in range(W, W + K):
             bufs[i].generate(n, seed=123 + i)
         DeviceUtils.waitForCompletion(d)
+        settle()   # the verification above left the chip idle for seconds
         d.toggleProfiling(True)
         d.profile(reset=True)
         for i in range(W, W + K):
             p.radixSort(d, bufs[i], n)
         prof = d.profile(reset=True)
         d.toggleProfiling(False)
+        if sb is not None:
+            sb.release()
 
         # empirical ceilings on this box (copy: read+write, read: read only)
         probe = {}
@@ -432,7 +450,10 @@ def main():
         workload = "Key-only RadixSort32, %d uniform-random u32 keys (splitmix64 hi32, seed 123+step), 1xMI355X, in place" % n
         auto = "auto (two MSD bucket passes + LDS finish at this size)" if large else "auto (one-sweep at this size)"
         algo_name = {0: "onesweep", 1: "three-kernel", -1: auto}.get(algo, str(algo))
-        cfg_extra = {"sort_algo": algo_name, "digit_bits": digit_bits}
+        cfg_extra = {"sort_algo": algo_name, "digit_bits": digit_bits,
+                     "clock_settle": {"untimed_sorts_before_warmup": settle_sorts,
+                                      "why": "the chip needs ~10 ms of sustained load after an idle gap to reach its steady clock; "
+                                             "the LDS-bound finish runs 20 % slower until then (profiles/r4_clock_ramp.txt)"}}
     else:
         from oclradixsort_amd.dist import HipBackend, ShardedRadixSort
         be = HipBackend(local_rank)

@@ -1400,7 +1400,7 @@ int launch_large_finish(adlhip_device* d, const E* slab_b, E* out, uint32_t* out
             const uint16_t* sb = reinterpret_cast<const uint16_t*>(slab_b);
 #define ADLHIP_F16(R2_, WAVES_)                                                                                                      \
     {                                                                                                                                \
-        auto kf = adlhip::wave_finish16_kernel<R2_, WAVES_, true>;                                                                   \
+        auto kf = adlhip::wave_finish16_kernel<R2_, WAVES_, true, true, 1>;                                                                   \
         const size_t lds = (size_t)WAVES_ * adlhip::Finish16Cfg<R2_>::PER_WAVE;                                                      \
         if (ensure_lds(kf, lds)) return ADLHIP_FAILURE;                                                                              \
         return launch(d, "segment_sort_wave_u32", [&] {                                                                              \

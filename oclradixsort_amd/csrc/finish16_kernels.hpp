@@ -30,7 +30,10 @@ struct Finish16Cfg {
 __device__ __forceinline__ uint32_t finish16_index(uint32_t p) { return (p & ~127u) | ((p & 63u) << 1) | ((p >> 6) & 1u); }
 
 // RR row pairs; the first RR - 1 are full (m > 128 (RR - 1)), only the last is tested per lane
-template <int RR, bool NT>
+// NTL / NTS: non-temporal loads of the slab / stores of the result.  ALG: 0 = count, scan, then a returning atomic per key hands out
+// its slot; 1 = ONE returning atomic per key counts and ranks (its arrival number inside its bin, in position order), then scan and
+// slot = bin start (a gather: cheaper than an atomic, tools/r4_lds_bench) + rank.
+template <int RR, bool NTL, bool NTS, int ALG>
 __device__ __forceinline__ void finish16_rows(const uint32_t* __restrict__ src32, uint32_t* __restrict__ out, uint32_t m, int lane,
                                               uint16_t* __restrict__ buf16, uint32_t* __restrict__ cnt, uint32_t low_bits, uint32_t hi)
 {
@@ -41,7 +44,7 @@ __device__ __forceinline__ void finish16_rows(const uint32_t* __restrict__ src32
     uint32_t kp[RR];
 #pragma unroll
     for (int j = 0; j < RR; ++j)
-        if (j < L || a_lo) kp[j] = NT ? __builtin_nontemporal_load(src32 + j * 64 + lane) : src32[j * 64 + lane];
+        if (j < L || a_lo) kp[j] = NTL ? __builtin_nontemporal_load(src32 + j * 64 + lane) : src32[j * 64 + lane];
     bool placed = false;   // wave-uniform: the keys sit in position order (a pass has run)
     const int npass = ((int)low_bits + 7) / 8;
     int sb = 0;
@@ -67,10 +70,18 @@ __device__ __forceinline__ void finish16_rows(const uint32_t* __restrict__ src32
         }
         const u32x4 z = {0u, 0u, 0u, 0u};
         *reinterpret_cast<u32x4*>(cnt + 4 * lane) = z;
+        uint32_t rk[RR];   // ALG 1: the two ranks of a register's keys
 #pragma unroll
         for (int j = 0; j < RR; ++j) {
-            if (j < L || v_lo) __hip_atomic_fetch_add(&cnt[dlo(kp[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (j < L || v_hi) __hip_atomic_fetch_add(&cnt[dhi(kp[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if constexpr (ALG == 0) {
+                if (j < L || v_lo) __hip_atomic_fetch_add(&cnt[dlo(kp[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (j < L || v_hi) __hip_atomic_fetch_add(&cnt[dhi(kp[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            } else {   // position order: row 2j before row 2j + 1, colliding lanes in lane order (stable)
+                uint32_t r0 = 0u, r1 = 0u;
+                if (j < L || v_lo) r0 = __hip_atomic_fetch_add(&cnt[dlo(kp[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (j < L || v_hi) r1 = __hip_atomic_fetch_add(&cnt[dhi(kp[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                rk[j] = r0 | (r1 << 16);
+            }
         }
         {   // counts -> bin starts
             const u32x4 c = *reinterpret_cast<const u32x4*>(cnt + 4 * lane);
@@ -83,15 +94,27 @@ __device__ __forceinline__ void finish16_rows(const uint32_t* __restrict__ src32
             o.w = o.z + c.z;
             *reinterpret_cast<u32x4*>(cnt + 4 * lane) = o;
         }
-        // slots: one returning atomic per key in position order (row 2j before row 2j + 1; colliding lanes are served in lane order:
-        // stable, radix_kernels.hpp rank_in_wave), then its 16-bit store
+        if constexpr (ALG == 0) {
+            // slots: one returning atomic per key in position order (row 2j before row 2j + 1; colliding lanes are served in lane
+            // order: stable, radix_kernels.hpp rank_in_wave), then its 16-bit store
 #pragma unroll
-        for (int j = 0; j < RR; ++j) {
-            uint32_t p0 = 0u, p1 = 0u;
-            if (j < L || v_lo) p0 = __hip_atomic_fetch_add(&cnt[dlo(kp[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (j < L || v_hi) p1 = __hip_atomic_fetch_add(&cnt[dhi(kp[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (j < L || v_lo) buf16[finish16_index(p0)] = (uint16_t)kp[j];
-            if (j < L || v_hi) buf16[finish16_index(p1)] = (uint16_t)(kp[j] >> 16);
+            for (int j = 0; j < RR; ++j) {
+                uint32_t p0 = 0u, p1 = 0u;
+                if (j < L || v_lo) p0 = __hip_atomic_fetch_add(&cnt[dlo(kp[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (j < L || v_hi) p1 = __hip_atomic_fetch_add(&cnt[dhi(kp[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (j < L || v_lo) buf16[finish16_index(p0)] = (uint16_t)kp[j];
+                if (j < L || v_hi) buf16[finish16_index(p1)] = (uint16_t)(kp[j] >> 16);
+            }
+        } else {
+            const volatile uint32_t* start = cnt;
+#pragma unroll
+            for (int j = 0; j < RR; ++j) {
+                uint32_t p0 = 0u, p1 = 0u;
+                if (j < L || v_lo) p0 = start[dlo(kp[j])] + (rk[j] & 0xffffu);
+                if (j < L || v_hi) p1 = start[dhi(kp[j])] + (rk[j] >> 16);
+                if (j < L || v_lo) buf16[finish16_index(p0)] = (uint16_t)kp[j];
+                if (j < L || v_hi) buf16[finish16_index(p1)] = (uint16_t)(kp[j] >> 16);
+            }
         }
 #pragma unroll
         for (int j = 0; j < RR; ++j)
@@ -103,11 +126,11 @@ __device__ __forceinline__ void finish16_rows(const uint32_t* __restrict__ src32
 #pragma unroll
         for (int j = 0; j < RR; ++j) {
             if (j < L || b_lo) {
-                if constexpr (NT) __builtin_nontemporal_store(hi | (kp[j] & 0xffffu), out + 128 * j + lane);
+                if constexpr (NTS) __builtin_nontemporal_store(hi | (kp[j] & 0xffffu), out + 128 * j + lane);
                 else out[128 * j + lane] = hi | (kp[j] & 0xffffu);
             }
             if (j < L || b_hi) {
-                if constexpr (NT) __builtin_nontemporal_store(hi | (kp[j] >> 16), out + 128 * j + 64 + lane);
+                if constexpr (NTS) __builtin_nontemporal_store(hi | (kp[j] >> 16), out + 128 * j + 64 + lane);
                 else out[128 * j + 64 + lane] = hi | (kp[j] >> 16);
             }
         }
@@ -120,22 +143,22 @@ __device__ __forceinline__ void finish16_rows(const uint32_t* __restrict__ src32
     }
 }
 
-template <int RR, int R2, bool NT>
+template <int RR, int R2, bool NTL, bool NTS, int ALG>
 __device__ __forceinline__ void finish16_dispatch(int rows2, const uint32_t* __restrict__ src32, uint32_t* __restrict__ out, uint32_t m,
                                                   int lane, uint16_t* __restrict__ buf16, uint32_t* __restrict__ cnt, uint32_t low_bits,
                                                   uint32_t hi)
 {
     if constexpr (RR >= R2) {
-        finish16_rows<R2, NT>(src32, out, m, lane, buf16, cnt, low_bits, hi);
+        finish16_rows<R2, NTL, NTS, ALG>(src32, out, m, lane, buf16, cnt, low_bits, hi);
     } else {
-        if (rows2 <= RR) finish16_rows<RR, NT>(src32, out, m, lane, buf16, cnt, low_bits, hi);
-        else finish16_dispatch<RR + 1, R2, NT>(rows2, src32, out, m, lane, buf16, cnt, low_bits, hi);
+        if (rows2 <= RR) finish16_rows<RR, NTL, NTS, ALG>(src32, out, m, lane, buf16, cnt, low_bits, hi);
+        else finish16_dispatch<RR + 1, R2, NTL, NTS, ALG>(rows2, src32, out, m, lane, buf16, cnt, low_bits, hi);
     }
 }
 
 // slab: 65536 segment slabs of `stride` uint16_t (stride even); segment s holds seg_cnt[s] keys and goes to out[seg_off[s] ...).
 // dyn[0] = bits the finish sorts (<= 16), dyn[1] = the keys' common prefix above the two digits (msd2_offsets_kernel).
-template <int R2, int WAVES, bool NT = false>
+template <int R2, int WAVES, bool NTL = false, bool NTS = false, int ALG = 0>
 __global__ __launch_bounds__(64 * WAVES) void wave_finish16_kernel(const uint16_t* __restrict__ slab, uint32_t* __restrict__ out,
                                                                     const uint32_t* __restrict__ seg_off,
                                                                     const uint32_t* __restrict__ seg_cnt, uint32_t stride,
@@ -162,7 +185,7 @@ __global__ __launch_bounds__(64 * WAVES) void wave_finish16_kernel(const uint16_
     }
     const uint32_t hi = ((dyn[1] << 16) | seg) << low_bits;
     const uint32_t* src32 = reinterpret_cast<const uint32_t*>(slab + (size_t)seg * stride);
-    finish16_dispatch<1, R2, NT>((int)((m + 127u) >> 7), src32, out + begin, m, lane, buf16, cnt, low_bits, hi);
+    finish16_dispatch<1, R2, NTL, NTS, ALG>((int)((m + 127u) >> 7), src32, out + begin, m, lane, buf16, cnt, low_bits, hi);
 }
 
 }   // namespace adlhip

@@ -1,7 +1,7 @@
 #!/bin/bash
 # bench + rocprof stats of the same command (+ the bench's own PMC child runs)
 export TMPDIR=/tmp
-TAG=${1:-r3_bench}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
+TAG=${1:-r4_bench}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 echo "== bench"; timeout -k 10 900 python bench.py 2>$OUT/bench.err | tail -1 | tee $OUT/bench_n1.json | cut -c1-600
 tail -5 $OUT/bench.err
 echo "== rocprofv3 --kernel-trace --stats (same command, without the PMC child runs and the CPU leg)"

@@ -50,33 +50,51 @@ __global__ void check_sorted(const uint32_t* k, uint32_t n, unsigned long long* 
     atomicXor(out + 2, x);
 }
 
+// event pairs around every launch, recorded WITHOUT synchronising (the launches of a configuration run back to back, as in bench.py:
+// the chip holds a lower clock under sustained load than between synchronised launches, and the LDS-bound finish shows it); all
+// pairs are read at report()
 struct Timer {
-    std::vector<std::pair<std::string, float>> acc;
-    std::vector<int> cnt;
-    hipEvent_t e0, e1;
-    Timer() { CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); }
+    struct Rec { std::string name; hipEvent_t e0, e1; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    hipEvent_t get()
+    {
+        if (used == pool.size()) { hipEvent_t e; CK(hipEventCreate(&e)); pool.push_back(e); }
+        return pool[used++];
+    }
     template <typename F>
     void run(const char* name, bool timed, F&& f)
     {
         if (!timed) { f(); return; }
-        CK(hipEventRecord(e0, 0));
+        Rec r{name, get(), get()};
+        CK(hipEventRecord(r.e0, 0));
         f();
-        CK(hipEventRecord(e1, 0));
-        CK(hipEventSynchronize(e1));
-        float ms = 0;
-        CK(hipEventElapsedTime(&ms, e0, e1));
-        for (size_t i = 0; i < acc.size(); ++i)
-            if (acc[i].first == name) { acc[i].second += ms; cnt[i]++; return; }
-        acc.push_back({name, ms});
-        cnt.push_back(1);
+        CK(hipEventRecord(r.e1, 0));
+        recs.push_back(r);
     }
     void report(const char* title)
     {
+        CK(hipDeviceSynchronize());
+        std::vector<std::pair<std::string, std::pair<float, int>>> acc;
+        for (auto& r : recs) {
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, r.e0, r.e1));
+            bool found = false;
+            for (auto& a : acc) if (a.first == r.name) { a.second.first += ms; a.second.second++; found = true; }
+            if (!found) acc.push_back({r.name, {ms, 1}});
+        }
+        if (getenv("R4_SEQ")) {   // per-launch durations of one launch kind, in order (us)
+            printf("  seq %s:", getenv("R4_SEQ"));
+            for (auto& r : recs) if (r.name == getenv("R4_SEQ")) { float ms = 0; CK(hipEventElapsedTime(&ms, r.e0, r.e1)); printf(" %.0f", ms * 1000); }
+            printf("\n");
+        }
         printf("  [%s]", title);
-        for (size_t i = 0; i < acc.size(); ++i) printf(" %s=%.4f", acc[i].first.c_str(), acc[i].second / cnt[i]);
-        printf("\n");
-        acc.clear();
-        cnt.clear();
+        float sum = 0;
+        for (auto& a : acc) { printf(" %s=%.4f", a.first.c_str(), a.second.first / a.second.second); sum += a.second.first / a.second.second; }
+        printf(" | sum=%.4f\n", sum);
+        recs.clear();
+        used = 0;
     }
 };
 
@@ -99,9 +117,13 @@ int main(int argc, char** argv)
     typedef uint32_t E;
     const uint32_t stride_a = (uint32_t)(((n / 256 + (n / 256) / 2 + 4096) + 63) / 64 * 64);
     const uint32_t stride_b = 1536, slots = 65536;
-    E *keys, *orig, *slab_a, *tmp;
+    // NB key buffers taken in turns, each restored three sorts before its turn: a sort reads keys that are cold in every cache and
+    // writes its result over them (as bench.py's steps do; ONE buffer restored right before its sort flatters pass 1 and the finish)
+    constexpr int NB = 6;
+    E *keys, *kbuf[NB], *orig, *slab_a, *tmp;
     uint16_t* slab_b;
-    CK(hipMalloc(&keys, n * 4));
+    for (int i = 0; i < NB; ++i) CK(hipMalloc(&kbuf[i], n * 4));
+    keys = kbuf[0];
     CK(hipMalloc(&orig, n * 4));
     CK(hipMalloc(&tmp, n * 4));
     CK(hipMalloc(&slab_a, (size_t)256 * stride_a * 4));
@@ -163,9 +185,12 @@ int main(int argc, char** argv)
     // one configuration = (pass kernels, finish); every iteration restores the input outside the timed launches
     auto chain = [&](const char* title, auto&& pass1, auto&& pass2, auto&& finish) {
         if (only[0] && !strstr(title, only)) return;
+        for (int i = 0; i < 3; ++i) CK(hipMemcpyAsync(kbuf[i], orig, n * 4, hipMemcpyDeviceToDevice, 0));
         for (int it = 0; it < iters + 3; ++it) {
             const bool timed = it >= 3;
-            CK(hipMemcpyAsync(keys, orig, n * 4, hipMemcpyDeviceToDevice, 0));
+            keys = kbuf[it % NB];
+            pa.src = keys;
+            CK(hipMemcpyAsync(kbuf[(it + 3) % NB], orig, n * 4, hipMemcpyDeviceToDevice, 0));
             T.run("sample", timed, [&] {
                 hipLaunchKernelGGL(msd2_sample_kernel<E>, dim3(kSampleWGs), dim3(64), 0, 0, (const E*)keys, (uint32_t)n, sample, bar, fault);
             });
@@ -213,27 +238,31 @@ int main(int argc, char** argv)
         snprintf(title, sizeof title, "persist %dx%d wg/cu=%d aux %d%d/%d%d %s", NT_, K_, WGS_, L1, S1, L2, S2, #FIN);           \
         chain(title, p1, p2, FIN);                                                                                               \
     }
-#define FIN16(NAME, WAVES_, NT_)                                                                                                 \
-    auto kf_##NAME = wave_finish16_kernel<12, WAVES_, NT_>;                                                                      \
+#define FIN16(NAME, WAVES_, NTL_, NTS_, ALG_)                                                                                    \
+    auto kf_##NAME = wave_finish16_kernel<12, WAVES_, NTL_, NTS_, ALG_>;                                                         \
     const size_t lds_##NAME = (size_t)WAVES_ * Finish16Cfg<12>::PER_WAVE;                                                        \
     ensure_lds(kf_##NAME, lds_##NAME);                                                                                           \
     auto NAME = [&] {                                                                                                            \
         hipLaunchKernelGGL(kf_##NAME, dim3(65536 / WAVES_), dim3(64 * WAVES_), lds_##NAME, 0, (const uint16_t*)slab_b, keys, seg_off,  \
                            seg_cnt, stride_b, mode, mode + kDynLowBits, 65536u, fault);                                          \
     };
-    FIN16(f16, 4, false)
-    FIN16(f16nt, 4, true)
-    PERSIST(512, 32, 2, 0, 0, 0, 0, f16)
-    PERSIST(512, 32, 2, 2, 0, 0, 0, f16)
-    PERSIST(512, 32, 2, 0, 2, 0, 0, f16)
-    PERSIST(512, 32, 2, 0, 0, 2, 0, f16)
-    PERSIST(512, 32, 2, 0, 0, 0, 2, f16)
-    PERSIST(512, 32, 2, 2, 0, 2, 0, f16)
-    PERSIST(512, 32, 2, 2, 2, 2, 2, f16)
-    PERSIST(512, 32, 2, 0, 0, 0, 0, f16nt)
-    PERSIST(512, 32, 2, 2, 0, 2, 0, f16nt)
-    PERSIST(512, 32, 1, 0, 0, 0, 0, f16)
-    PERSIST(1024, 32, 1, 0, 0, 0, 0, f16)
-    PERSIST(512, 32, 2, 0, 0, 0, 0, f_old)
+    FIN16(f16_00_a0, 4, false, false, 0)
+    FIN16(f16_10_a0, 4, true, false, 0)
+    FIN16(f16_01_a0, 4, false, true, 0)
+    FIN16(f16_11_a0, 4, true, true, 0)
+    FIN16(f16_00_a1, 4, false, false, 1)
+    FIN16(f16_10_a1, 4, true, false, 1)
+    FIN16(f16_11_a1, 4, true, true, 1)
+    FIN16(f16_10_a1_w8, 8, true, false, 1)
+    PERSIST(512, 32, 2, 2, 0, 2, 0, f_old)
+    PERSIST(512, 32, 2, 2, 0, 2, 0, f16_00_a0)
+    PERSIST(512, 32, 2, 2, 0, 2, 0, f16_10_a0)
+    PERSIST(512, 32, 2, 2, 0, 2, 0, f16_01_a0)
+    PERSIST(512, 32, 2, 2, 0, 2, 0, f16_11_a0)
+    PERSIST(512, 32, 2, 2, 0, 2, 0, f16_00_a1)
+    PERSIST(512, 32, 2, 2, 0, 2, 0, f16_10_a1)
+    PERSIST(512, 32, 2, 2, 0, 2, 0, f16_11_a1)
+    PERSIST(512, 32, 2, 2, 0, 2, 0, f16_10_a1_w8)
+    PERSIST(512, 32, 2, 0, 0, 0, 0, f16_00_a0)
     return 0;
 }
