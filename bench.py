@@ -87,6 +87,13 @@ PMC_KERNEL = {
     "msd2_pass2_u32": "msd_scatter_persist_kernel<unsigned int, 512, 32, 2,",
     "segment_sort_wave_u32": "wave_finish16_kernel<",
     "onesweep_u32_8b": "onesweep_chain_kernel",
+    # configs #3 and #5 (both look-back passes of a sort are one kernel; the counters are averaged over the two)
+    "msd2s_pass1_kv32": "msd_lookback_scatter_kernel<unsigned long, 512, 16, false>",
+    "msd2s_pass2_kv32": "msd_lookback_scatter_kernel<unsigned long, 512, 16, false>",
+    "segment_sort_wave_e64": "wave_segment_sort_kernel<unsigned long, 24,",
+    "msd2s_pass1_u64": "msd_lookback_scatter_kernel<unsigned long, 512, 16, true>",
+    "msd2s_pass2_u64": "msd_lookback_scatter_kernel<unsigned long, 512, 16, true>",
+    "segment_sort_bin_u64": "bin_segment_sort_kernel<unsigned long",
 }
 
 
@@ -103,6 +110,16 @@ def pmc_child(n, steps):
     DeviceUtils.waitForCompletion(d)
     for b in bufs:
         b.release()
+    if n == N_KEYS:   # configs #3 and #5: two sorts each
+        for nn, gen, fn in ((1 << 26, 1, p.radixSort), (1 << 28, 2, p.radixSort64)):
+            bb = [Buffer(d, nn, np.uint64) for _ in range(2)]
+            for i, b in enumerate(bb):
+                b.generate(nn, seed=900 + i, kind=gen)
+            for b in bb:
+                fn(d, b, nn)
+            DeviceUtils.waitForCompletion(d)
+            for b in bb:
+                b.release()
     p.close()
     DeviceUtils.deallocate(d)
 
@@ -127,7 +144,21 @@ def measure_traffic(n, launch_names):
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--n", str(n), "--steps", "3"]
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            # a process group of its own: on a timeout the profiler AND the Python child under it are killed -- a survivor would
+            # keep its buffers on the GPU and run beside the timed region
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=300)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                proc.wait()
+                raise
+            if rc != 0:
+                raise RuntimeError("rocprofv3 %s pass failed with code %d" % (ctr, rc))
             acc = {k: [0.0, 0] for k in launch_names}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
@@ -314,23 +345,72 @@ def main():
         if sb is not None:
             sb.release()
 
-        # empirical ceilings on this box (copy: read+write, read: read only)
+        # Empirical ceilings on this box, measured on buffers that are COLD in every cache (the K + W key buffers in turns: 6.7 GB,
+        # 25 x the Infinity Cache -- a probe that copies the same 256 MiB over and over reads its source out of that cache and reports
+        # what no sweep of a sort can reach).  Every variant: plain / non-temporal loads / non-temporal stores / both, 8 workgroups
+        # of 256 threads per CU.  copy = read + written bytes per second; the best variant is the ceiling rooflines are also quoted
+        # against (`frac_of_copy`).
         probe = {}
-        a, b2 = bufs[0], bufs[1]
         lib = __import__("oclradixsort_amd._lib", fromlist=["load"]).load()
         sink = Buffer(d, 2, np.uint64)
         sink.clear()
-        for name, fn, nbytes in (("copy", lambda: lib.adlhip_probe_copy(d._h, a.ptr(), b2.ptr(), n * 4), 2 * n * 4),
-                                 ("read", lambda: lib.adlhip_probe_read(d._h, a.ptr(), n * 4, sink.ptr()), n * 4)):
-            for _ in range(3):
-                fn()
+        nb = len(bufs)
+
+        def rate(fn, nbytes, reps=12):
+            for r in range(3):
+                fn(r)
             s2 = Stopwatch(d)
             s2.start()
-            for _ in range(10):
-                fn()
+            for r in range(reps):
+                fn(3 + r)
             s2.stop()
-            probe[name + "_GBps"] = nbytes * 10 / (s2.getMs() * 1e-3) / 1e9
+            return nbytes * reps / (s2.getMs() * 1e-3) / 1e9
+
+        if nb >= 4:
+            for hints, tag in ((0, "plain"), (1, "nt_loads"), (2, "nt_stores"), (3, "nt_both")):
+                probe["copy_%s_GBps" % tag] = rate(lambda r, h=hints: lib.adlhip_probe_copy_ex(
+                    d._h, bufs[(2 * r + 1) % nb].ptr(), bufs[(2 * r) % nb].ptr(), n * 4, h, 8), 2 * n * 4)
+            for hints, tag in ((0, "plain"), (1, "nt_loads")):
+                probe["read_%s_GBps" % tag] = rate(lambda r, h=hints: lib.adlhip_probe_read_ex(
+                    d._h, bufs[r % nb].ptr(), n * 4, sink.ptr(), h, 8), n * 4)
+            probe["copy_GBps"] = max(v for k, v in probe.items() if k.startswith("copy_"))
+            probe["read_GBps"] = max(v for k, v in probe.items() if k.startswith("read_"))
+            probe["buffers"] = "cold: %d key buffers of %d MiB in turns" % (nb, n * 4 >> 20)
         sink.release()
+
+        # The literal "HBM-READ roofline" of the metric: the digit histogram (radix_count_kernel = the reference's StreamCountKernel,
+        # RadixSort32Kernels.cl:176-236), a pure read stream of n keys -- measured where the library runs it on cold input: as the
+        # first of the three launches of the multi-GPU partition (adlhip_partition_top_byte_u32), profiled per launch.
+        hbm_read = None
+        try:
+            if nb >= 4:
+                import ctypes as ct
+                tb, wb = ct.c_size_t(), ct.c_size_t()
+                lib.adlhip_radix_sort_scratch_bytes(d._h, 0, n, ct.byref(tb), ct.byref(wb))
+                pw = Buffer(d, wb.value + wb.value // 8, np.uint8)
+                pt = Buffer(d, 256, np.uint32)
+                d.toggleProfiling(True)
+                d.profile(reset=True)
+                for r in range(8):
+                    rc = lib.adlhip_partition_top_byte_u32(d._h, bufs[(2 * r) % nb].ptr(), bufs[(2 * r + 1) % nb].ptr(), pt.ptr(), pw.ptr(),
+                                                           pw.getSize(), n)
+                    if rc:
+                        raise RuntimeError("adlhip_partition_top_byte_u32 failed")
+                pprof = d.profile(reset=True)
+                d.toggleProfiling(False)
+                pw.release()
+                pt.release()
+                ck = [k for k in pprof if k.startswith("count_")]
+                if ck:
+                    ln, ms = pprof[ck[0]][0], pprof[ck[0]][1]
+                    ach = n * ELEM_BYTES / (ms / ln * 1e-3) / 1e9
+                    hbm_read = {"kernel": ck[0], "rocprof_kernel": "radix_count_kernel<unsigned int, 8, 256>", "launches": ln,
+                                "avg_launch_ms": ms / ln, "algorithmic_bytes_per_launch": n * ELEM_BYTES, "achieved": ach,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                "frac_of_read_probe": ach / probe["read_GBps"] if probe.get("read_GBps") else None,
+                                "where": "first launch of adlhip_partition_top_byte_u32 on keys that are cold in every cache"}
+        except Exception as e:
+            hbm_read = {"error": repr(e)[:300]}
 
         algo = d.getParam("sort.algo")
         digit_bits = d.getParam("sort.digit_bits")
@@ -358,6 +438,31 @@ def main():
                     s3.stop()
                     ms = s3.getMs() / reps
                     entry = {"value": nn / ms / 1e6, "unit": unit, "ms_per_sort": ms, "elements": nn, "sorts_timed": reps}
+                    # every sweep of this sort priced as config #2's are: algorithmic bytes (8 read + 8 written per 8-byte element
+                    # and sweep) over the launch's mean time between two events
+                    for i, b in enumerate(bb[3:5]):   # (bb[1] is checked against the oracle below)
+                        b.generate(nn, seed=950 + i, kind=gen)
+                    d.toggleProfiling(True)
+                    d.profile(reset=True)
+                    for b in bb[3:5]:
+                        sorter(b, nn)
+                    oprof = d.profile(reset=True)
+                    d.toggleProfiling(False)
+                    rows = []
+                    for k, v in oprof.items():
+                        if k.startswith(("msd2s_pass", "msd2_pass", "msd2h_pass", "segment_sort", "onesweep_", "scatter_")) and v[1] / v[0] > 0.02:
+                            by = 2 * nn * 8
+                            ach = by / (v[1] / v[0] * 1e-3) / 1e9
+                            row = {"kernel": k, "rocprof_kernel": PMC_KERNEL.get(k), "launches": v[0], "avg_launch_ms": v[1] / v[0],
+                                   "algorithmic_bytes_per_launch": by, "achieved": ach, "frac": ach / HBM_PEAK_GBS}
+                            t = pmc_traffic.get(k) if isinstance(pmc_traffic, dict) else None
+                            if isinstance(t, dict) and "traffic_bytes_per_launch" in t:
+                                row["traffic"] = t["traffic_bytes_per_launch"]
+                            rows.append(row)
+                    rows.sort(key=lambda r: -r["avg_launch_ms"] * r["launches"])
+                    if rows:
+                        entry["roofline"] = dict(rows[0], bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", by_kernel=rows)
+                    entry["kernels"] = {k: {"launches": v[0], "avg_ms": v[1] / v[0]} for k, v in oprof.items()}
                     if not args.no_verify:   # outside the timing: one result against the oracle, bit for bit
                         import oracle
                         got = bb[1].toHost()
@@ -434,6 +539,11 @@ def main():
         }
         if "error" in traffic_all:
             out["roofline"]["traffic_error"] = traffic_all["error"]
+        if probe.get("copy_GBps"):
+            out["roofline"]["frac_of_copy"] = achieved / probe["copy_GBps"]
+            for row in by_kernel:
+                row["frac_of_copy"] = row["achieved"] / probe["copy_GBps"]
+        out["roofline"]["hbm_read"] = hbm_read
         out["kernels"] = {k: {"launches": v[0], "avg_ms": v[1] / v[0]} for k, v in prof.items()}
         out["probe"] = probe
         out["device"] = info_name

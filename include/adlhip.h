@@ -352,6 +352,11 @@ int adlhip_profile_write_csv(adlhip_device* dev, const char* path);
 /* ---- bandwidth probes (diagnostics for bench.py: empirical HBM ceilings) ---------------------- */
 int adlhip_probe_copy(adlhip_device* dev, void* d_dst, const void* d_src, size_t bytes);
 int adlhip_probe_read(adlhip_device* dev, const void* d_src, size_t bytes, void* d_sink8);
+/* The same with cache-policy hints (hints bit 0 = non-temporal loads, bit 1 = non-temporal stores) and a choice of grid
+ * (grid_per_cu workgroups of 256 threads per CU, 0 = 8): bench.py measures every variant on buffers that are cold in every
+ * cache and reports the best one as the copy / read ceiling of the box. */
+int adlhip_probe_copy_ex(adlhip_device* dev, void* d_dst, const void* d_src, size_t bytes, int hints, int grid_per_cu);
+int adlhip_probe_read_ex(adlhip_device* dev, const void* d_src, size_t bytes, void* d_sink8, int hints, int grid_per_cu);
 
 /* Re-runs the device self-test that "sort.rank" = 1 rests on (returning DS atomics of one wave instruction
  * resolve colliding lanes in ascending lane order; ranks are compared with ballot/mbcnt ranks) with `workgroups`

@@ -90,6 +90,8 @@ SIGNATURES = {
     "adlhip_profile_write_csv": (_I, [_VP, ctypes.c_char_p]),
     "adlhip_probe_copy": (_I, [_VP, _VP, _VP, _SZ]),
     "adlhip_probe_read": (_I, [_VP, _VP, _SZ, _VP]),
+    "adlhip_probe_copy_ex": (_I, [_VP, _VP, _VP, _SZ, _I, _I]),
+    "adlhip_probe_read_ex": (_I, [_VP, _VP, _SZ, _VP, _I, _I]),
     "adlhip_selftest_lds_order": (_I, [_VP, _I, ctypes.POINTER(ctypes.c_uint32)]),
     "adlhip_selftest_probe_positions": (_I, [_VP, _SZ, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     "adlhip_version": (ctypes.c_char_p, []),

@@ -1372,7 +1372,10 @@ LargeForm large_sort_form(const adlhip_device* d, size_t elem_bytes, bool keys, 
     if (d->msd2_path == 5) return n <= kMsd2sMax ? kLargeHybrid : kLargeNone;
     // profiles/r3_forms_by_size.txt -- u32 keys: cursor | hybrid 64 Mi 0.424 | 0.423 ms, 128 Mi 0.782 | 0.751, 256 Mi 1.700 | 1.620
     // (16 Mi: 0.140 | 0.159); u64 keys: cursor | stable 16 Mi 0.294 | 0.312, 64 Mi 0.846 | 0.803, 256 Mi 3.18 | 2.99 (hybrid 2.96)
-    if (elem_bytes == 4 && n >= (size_t(96) << 20) && n <= kMsd2sMax) return kLargeHybrid;
+    // round 4 (profiles/r4_forms_by_size.txt, persistent cursor passes): u32 keys cursor | hybrid 64 Mi 0.355 | 0.420 ms, 96 Mi 0.559 | 0.585,
+    // 128 Mi 0.688 | 0.743, 256 Mi 1.496 | 1.436 -- the cursor-placed first pass loses ground with n (4.3 TB/s at 64 Mi, 3.4 at 256 Mi)
+    const size_t hybrid_min = d->persist ? (size_t(192) << 20) : (size_t(96) << 20);
+    if (elem_bytes == 4 && n >= hybrid_min && n <= kMsd2sMax) return kLargeHybrid;
     if (elem_bytes == 8 && n >= (size_t(48) << 20) && n <= kMsd2sMax) return kLargeStable;
     return n <= cursor_max ? kLargeCursor : kLargeNone;
 }
@@ -2606,6 +2609,37 @@ int adlhip_probe_copy(adlhip_device* d, void* dst, const void* src, size_t bytes
     const int grid = (int)std::min<size_t>((nvec + 255) / 256, (size_t)d->prop.multiProcessorCount * 8);
     return launch(d, "probe_copy", [&] {
         hipLaunchKernelGGL(adlhip::probe_copy_kernel, dim3(grid), dim3(256), 0, d->stream, (uint4*)dst, (const uint4*)src, nvec);
+    });
+}
+
+// hints: bit 0 = non-temporal loads, bit 1 = non-temporal stores; grid_per_cu workgroups of 256 threads per CU (0 = 8)
+int adlhip_probe_copy_ex(adlhip_device* d, void* dst, const void* src, size_t bytes, int hints, int grid_per_cu)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (hints < 0 || hints > 3 || grid_per_cu < 0 || grid_per_cu > 64) return fail("bad probe variant");
+    const size_t nvec = bytes / 16;
+    if (nvec == 0) return ADLHIP_SUCCESS;
+    const int grid = (int)std::min<size_t>((nvec + 255) / 256, (size_t)d->prop.multiProcessorCount * (grid_per_cu ? grid_per_cu : 8));
+    return launch(d, "probe_copy", [&] {
+        switch (hints) {
+        case 0: hipLaunchKernelGGL((adlhip::probe_copy_hint_kernel<false, false>), dim3(grid), dim3(256), 0, d->stream, (uint4*)dst, (const uint4*)src, nvec); break;
+        case 1: hipLaunchKernelGGL((adlhip::probe_copy_hint_kernel<true, false>), dim3(grid), dim3(256), 0, d->stream, (uint4*)dst, (const uint4*)src, nvec); break;
+        case 2: hipLaunchKernelGGL((adlhip::probe_copy_hint_kernel<false, true>), dim3(grid), dim3(256), 0, d->stream, (uint4*)dst, (const uint4*)src, nvec); break;
+        default: hipLaunchKernelGGL((adlhip::probe_copy_hint_kernel<true, true>), dim3(grid), dim3(256), 0, d->stream, (uint4*)dst, (const uint4*)src, nvec); break;
+        }
+    });
+}
+
+int adlhip_probe_read_ex(adlhip_device* d, const void* src, size_t bytes, void* sink8, int hints, int grid_per_cu)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (hints < 0 || hints > 1 || grid_per_cu < 0 || grid_per_cu > 64) return fail("bad probe variant");
+    const size_t nvec = bytes / 16;
+    if (nvec == 0) return ADLHIP_SUCCESS;
+    const int grid = (int)std::min<size_t>((nvec + 255) / 256, (size_t)d->prop.multiProcessorCount * (grid_per_cu ? grid_per_cu : 8));
+    return launch(d, "probe_read", [&] {
+        if (hints) hipLaunchKernelGGL((adlhip::probe_read_hint_kernel<true>), dim3(grid), dim3(256), 0, d->stream, (const uint4*)src, nvec, (unsigned long long*)sink8);
+        else hipLaunchKernelGGL((adlhip::probe_read_hint_kernel<false>), dim3(grid), dim3(256), 0, d->stream, (const uint4*)src, nvec, (unsigned long long*)sink8);
     });
 }
 

@@ -413,7 +413,7 @@ __device__ __forceinline__ void wave_sort_rows(const S* __restrict__ src, E* __r
     E e[R];
 #pragma unroll
     for (int j = 0; j < R; ++j)
-        if (j < F || j * 64 < rem) e[j] = (E)src[j * 64 + lane];
+        if (j < F || j * 64 < rem) e[j] = (E)load_once(src + j * 64 + lane);
     const int npass = ((int)low_bits + 7) / 8;   // 8-bit digits at most, as even as possible (u64 keys: up to six passes)
     if (npass == 0) {   // nothing left to sort (the digits above covered every bit that varies): the segment only moves
 #pragma unroll
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(NT) void wg_segment_sort_kernel(const S* __restrict
     E e[K];
 #pragma unroll
     for (int j = 0; j < K; ++j)
-        if (j < keff) e[j] = (j * 64 < rem) ? (E)src[wbase + (uint32_t)(j * 64)] : E(0);
+        if (j < keff) e[j] = (j * 64 < rem) ? (E)load_once(src + wbase + (uint32_t)(j * 64)) : E(0);
     int sb = 0;
     for (int p = 0; p < npass; ++p) {
         const int nb = ((int)low_bits - sb + (npass - p - 1)) / (npass - p);
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void bin_segment_sort_kern
         const S* __restrict__ src = in + (size_t)seg * in_stride;
 #pragma unroll
         for (int j = 0; j < K; ++j)
-            if ((uint32_t)(j * NT + tid0) < m && m <= (uint32_t)CAP) e[j] = src[j * NT + tid0];
+            if ((uint32_t)(j * NT + tid0) < m && m <= (uint32_t)CAP) e[j] = load_once(src + j * NT + tid0);
     }
     for (;;) {
         // the thread index, hidden from loop-invariant code motion: hoisted out of the loop, the addresses derived from it took a
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void bin_segment_sort_kern
                 const S* __restrict__ src = in + (size_t)next * in_stride;
 #pragma unroll
                 for (int j = 0; j < K; ++j)
-                    if ((uint32_t)(j * NT + tid) < m_next && m_next <= (uint32_t)CAP) e[j] = src[j * NT + tid];
+                    if ((uint32_t)(j * NT + tid) < m_next && m_next <= (uint32_t)CAP) e[j] = load_once(src + j * NT + tid);
             }
         };
         const bool sortable = m != 0u && m <= (uint32_t)CAP && low_bits != 0u;
@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
         for (int j = 0; j < K; ++j) {
             const uint32_t q = q0 + (uint32_t)(j * 64);
             while (c < 31u && q >= s_end[c]) ++c;
-            e[j] = (j * 64 < rem) ? a.src[(size_t)(q + s_adj[c])] : ~E(0);
+            e[j] = (j * 64 < rem) ? load_once(a.src + (size_t)(q + s_adj[c])) : ~E(0);
         }
     } else if (PASS == 3 && reinterpret_cast<const uint32_t*>(smem + C::OFF_MISC)[4] < valid) {
         // two stretches: tile positions below `split` come from the first sub-slab, the others from the next one
@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const uint32_t i = wbase + (uint32_t)(j * 64);
-            e[j] = (j * 64 < rem) ? a.src[(size_t)((i < split ? lin : ln2) + i)] : ~E(0);
+            e[j] = (j * 64 < rem) ? load_once(a.src + (size_t)((i < split ? lin : ln2) + i)) : ~E(0);
         }
     } else {
         const typename IO::Cursor p = io.cursor((size_t)(PASS == 3 ? lin : base) + wbase);
@@ -1634,7 +1634,7 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
         for (int j = 0; j < K; ++j) {
             const uint32_t q = q0 + (uint32_t)(j * 64);
             while (c < 31u && q >= s_end[c]) ++c;
-            e[j] = (j * 64 < rem) ? a.src[(size_t)(q + s_adj[c])] : ~E(0);
+            e[j] = (j * 64 < rem) ? load_once(a.src + (size_t)(q + s_adj[c])) : ~E(0);
         }
     }
     if (a.which_digit == 1 && a.place->top < (KEY64 ? 64u : 32u)) {   // a key outside the sampled range would land in a wrong bucket

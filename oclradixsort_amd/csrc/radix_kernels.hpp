@@ -152,6 +152,23 @@ struct TileCfg {
 //             SortAndScatterKernel(gSrc, gSrcVal, ...) (RadixSortKeyValueKernels.cl:354-509).
 //             A pair travels through registers and LDS as one u64 {key low, value high}, so the tile body
 //             is the one the AoS pairs use; only the global loads/stores differ.
+// Key loads of the one-tile-per-workgroup sweeps.  Round 4 A/B (profiles/r4_nt_loads_ab.txt): non-temporal loads help a sweep that
+// reads COLD data (first look-back pass of 64 Mi pairs 0.255 -> 0.245 ms) and hurt one that reads what the sweep before it has just
+// written (wave-per-segment finish of pairs 0.198 -> 0.226 ms, hybrid second pass 0.227 -> 0.248): plain loads stay the default
+// here (-DADLHIP_NT_LOADS=1 builds the partner); the persistent passes (persist_kernels.hpp) choose per pass.
+#ifndef ADLHIP_NT_LOADS
+#define ADLHIP_NT_LOADS 0
+#endif
+template <typename T>
+__device__ __forceinline__ T load_once(const T* p)
+{
+#if ADLHIP_NT_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 template <typename E>
 struct AosIO {
     typedef E elem_t;
@@ -160,7 +177,7 @@ struct AosIO {
     // cursor = one 64-bit pointer per tile; elements are then read at constant offsets from it
     struct Cursor {
         const E* p;
-        __device__ __forceinline__ E at(int off) const { return p[off]; }
+        __device__ __forceinline__ E at(int off) const { return load_once(p + off); }
     };
     __device__ __forceinline__ Cursor cursor(size_t base) const { return Cursor{src + base}; }
     __device__ __forceinline__ void store(size_t i, E v) const { dst[i] = v; }
@@ -194,7 +211,7 @@ struct SoaIO {
     struct Cursor {
         const uint32_t* k;
         const uint32_t* v;
-        __device__ __forceinline__ uint64_t at(int off) const { return (uint64_t)k[off] | ((uint64_t)v[off] << 32); }
+        __device__ __forceinline__ uint64_t at(int off) const { return (uint64_t)load_once(k + off) | ((uint64_t)load_once(v + off) << 32); }
     };
     __device__ __forceinline__ Cursor cursor(size_t base) const { return Cursor{ksrc + base, vsrc + base}; }
     __device__ __forceinline__ void store(size_t i, uint64_t v) const
@@ -533,7 +550,12 @@ __global__ __launch_bounds__(NT) void radix_count_kernel(const E* __restrict__ s
     for (int i = tid; i < BINS * COPIES; i += NT) hist[i] = 0u;
     __syncthreads();
 
-    const uint32_t wg = blockIdx.x;
+    // Which range a workgroup counts: workgroups b and b + 8 run on one XCD (speed only), and the table is bucket-major -- thread d
+    // writes ONE word into row d at the column of its range.  With range = workgroup index the columns an XCD writes are 8 apart
+    // (32 bytes): every 64-byte piece of a row is written by two XCDs and leaves each L2 half-filled.  With the ranges dealt so that
+    // an XCD's workgroups own CONSECUTIVE columns, whole lines are completed in one L2 (64 Mi keys, cold: 55 -> 4x us).
+    uint32_t wg = blockIdx.x;
+    if ((n_wgs & 7) == 0) wg = (blockIdx.x & 7u) * ((uint32_t)n_wgs >> 3) + (blockIdx.x >> 3);
     const uint64_t begin64 = (uint64_t)wg * elems_per_wg;
     if (begin64 < n) {
         const uint32_t begin = (uint32_t)begin64;
@@ -569,21 +591,32 @@ __global__ __launch_bounds__(NT) void radix_count_kernel(const E* __restrict__ s
             for (int k = 0; k < V; ++k) { bump(a.v[k]); bump(b.v[k]); bump(c.v[k]); bump(d4.v[k]); }
         };
         const uint32_t nvec = (end - begin) / VEC;
-        const Vec* vsrc = reinterpret_cast<const Vec*>(src + begin);
+        // every key is read once: NON-TEMPORAL 16-byte loads.  Round 4, 64 Mi u32 keys cold in every cache (tools/r4_probe hist,
+        // profiles/r4_hist_read_variants.txt): this kernel 55.2 us with plain loads; a bare read of the same bytes 48.9 us plain and
+        // 42.0-43.5 us non-temporal (6.2-6.4 TB/s); the histogram on non-temporal loads 42.8-43.9 us = 6.1-6.3 TB/s = 0.77 of 8 TB/s --
+        // the LDS atomics (8.8 cycles per 64 keys, tools/r4_lds_bench: 17 us of LDS time) hide behind the stream entirely.
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        const v4u* vraw = reinterpret_cast<const v4u*>(src + begin);
+        auto vld = [&](uint32_t at) -> Vec {
+            const v4u r = __builtin_nontemporal_load(vraw + at);
+            Vec o;
+            __builtin_memcpy(&o, &r, 16);
+            return o;
+        };
         uint32_t i = (uint32_t)tid;
         // 4 independent 16-byte loads in flight per lane
         if (i + 3u * NT < nvec) {   // software-pipelined: next loads in flight while the current vectors are counted
-            Vec a = vsrc[i], b = vsrc[i + NT], c = vsrc[i + 2 * NT], d4 = vsrc[i + 3 * NT];
+            Vec a = vld(i), b = vld(i + NT), c = vld(i + 2 * NT), d4 = vld(i + 3 * NT);
             i += 4u * NT;
             for (; i + 3u * NT < nvec; i += 4u * NT) {
-                const Vec na = vsrc[i], nb = vsrc[i + NT], nc = vsrc[i + 2 * NT], nd = vsrc[i + 3 * NT];
+                const Vec na = vld(i), nb = vld(i + NT), nc = vld(i + 2 * NT), nd = vld(i + 3 * NT);
                 bump4(a, b, c, d4);
                 a = na; b = nb; c = nc; d4 = nd;
             }
             bump4(a, b, c, d4);
         }
         for (; i < nvec; i += NT) {
-            Vec a = vsrc[i];
+            Vec a = vld(i);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) bump(a.v[k]);
         }
@@ -939,6 +972,44 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(uint4* __restrict__ dst
         dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
     }
     for (; i < nvec; i += stride) dst[i] = src[i];
+}
+
+// The same two probes with cache-policy hints: NTL = non-temporal loads, NTS = non-temporal stores (bench.py reports the plain and
+// the hinted rates side by side; which one is the honest ceiling for a sweep depends on whether the sweep's data will be read again)
+template <bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void probe_copy_hint_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t nvec)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u* s = reinterpret_cast<const v4u*>(src);
+    v4u* d = reinterpret_cast<v4u*>(dst);
+    auto ld = [&](size_t i) -> v4u { return NTL ? __builtin_nontemporal_load(s + i) : s[i]; };
+    auto st = [&](size_t i, v4u v) {
+        if (NTS) __builtin_nontemporal_store(v, d + i);
+        else d[i] = v;
+    };
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        const v4u a = ld(i), b = ld(i + stride), c = ld(i + 2 * stride), e = ld(i + 3 * stride);
+        st(i, a); st(i + stride, b); st(i + 2 * stride, c); st(i + 3 * stride, e);
+    }
+    for (; i < nvec; i += stride) st(i, ld(i));
+}
+template <bool NTL>
+__global__ __launch_bounds__(256) void probe_read_hint_kernel(const uint4* __restrict__ src, size_t nvec, unsigned long long* __restrict__ sink)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u* s = reinterpret_cast<const v4u*>(src);
+    auto ld = [&](size_t i) -> v4u { return NTL ? __builtin_nontemporal_load(s + i) : s[i]; };
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t acc = 0u;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        const v4u a = ld(i), b = ld(i + stride), c = ld(i + 2 * stride), e = ld(i + 3 * stride);
+        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ e.x ^ e.y ^ e.z ^ e.w;
+    }
+    for (; i < nvec; i += stride) { const v4u a = ld(i); acc ^= a.x ^ a.y ^ a.z ^ a.w; }
+    if (acc == 0x9e3779b9u) atomicAdd(sink, 1ull);   // practically never; keeps the loads alive
 }
 
 __global__ __launch_bounds__(256) void probe_read_kernel(const uint4* __restrict__ src, size_t nvec,

@@ -1569,7 +1569,7 @@ def test_small_partition_keeps_off_the_paths_with_a_grid_barrier(dev):
 
 
 def test_hybrid_form_whole_u32_keys(dev):
-    """Whole u32 keys through the hybrid form ("sort.msd2" = 5; the automatic choice from 96 Mi keys): stable first pass into
+    """Whole u32 keys through the hybrid form ("sort.msd2" = 5; the automatic choice from 192 Mi keys): stable first pass into
     sub-slabs, cursor-placed second pass over buckets made of those sub-slabs (tiles inside one sub-slab, across two, across
     many), 16-bit second slab.  Friendly, narrow, skewed (safety net) and outlier keys; bit-exact against the oracle."""
     dev.setParam("sort.msd2", 5)
@@ -1596,11 +1596,16 @@ def test_hybrid_form_whole_u32_keys(dev):
         k[12345] = 0xf0000001
         assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), "outlier above the sampled range"
         DeviceUtils.waitForCompletion(dev)
-        dev.setParam("sort.msd2", 2)   # the automatic forms: 128 Mi + 5 keys take the hybrid form
+        dev.setParam("sort.msd2", 2)   # the automatic forms: 200 Mi + 5 keys take the hybrid form (round 4: from 192 Mi keys; the
+        n = (200 << 20) + 5            # persistent cursor passes are the faster ones below), 128 Mi + 5 keys the cursor form
+        k = oracle.keys_u32(n, seed=55)
+        got, prof = _profiled(dev, lambda: gpu_sort_u32(dev, p, k))
+        assert {"msd2s_pass1_u32", "msd2h_pass2_u32"} <= set(prof), prof
+        assert np.array_equal(got, oracle.sort_u32(k))
         n = (1 << 27) + 5
         k = oracle.keys_u32(n, seed=55)
         got, prof = _profiled(dev, lambda: gpu_sort_u32(dev, p, k))
-        assert {"msd2s_pass1_u32", "msd2h_pass2_u32", "segment_sort_wave_u32"} <= set(prof), prof
+        assert {"msd2_pass1_u32", "msd2_pass2_u32", "segment_sort_wave_u32"} <= set(prof), prof
         assert np.array_equal(got, oracle.sort_u32(k))
     finally:
         dev.setParam("sort.msd2", 1)

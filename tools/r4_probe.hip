@@ -53,6 +53,57 @@ __global__ void check_sorted(const uint32_t* k, uint32_t n, unsigned long long* 
 // event pairs around every launch, recorded WITHOUT synchronising (the launches of a configuration run back to back, as in bench.py:
 // the chip holds a lower clock under sustained load than between synchronised launches, and the LDS-bound finish shows it); all
 // pairs are read at report()
+// ---- histogram / read variants (the literal "HBM-read roofline" of the metric) ----------------------------------------------------
+// MODE 0: xor-reduce only (read ceiling); 1: one ds_add per key on the wave's own 256 counters; 2: as 1 with the keys of a 16-byte
+// load counted in one packed pass (two keys per ... no: plain).  NTL: non-temporal loads.  U: 16-byte loads in flight per lane.
+template <int MODE, bool NTL, int U>
+__global__ __launch_bounds__(256) void hist_variant_kernel(const uint4* __restrict__ src, uint32_t nvec, uint32_t* __restrict__ table,
+                                                          int start_bit)
+{
+    __shared__ uint32_t hist[4 * 256];
+    const int tid = threadIdx.x, w = tid >> 6;
+    for (int i = tid; i < 4 * 256; i += 256) hist[i] = 0u;
+    __syncthreads();
+    uint32_t* my = hist + w * 256;
+    // contiguous chunk per workgroup, U loads in flight per lane
+    const uint32_t per_wg = (nvec + gridDim.x - 1) / gridDim.x;
+    const uint32_t begin = blockIdx.x * per_wg, end = min(nvec, begin + per_wg);
+    uint32_t acc = 0u;
+    auto ld = [&](uint32_t i) -> uint4 {
+        if (NTL) { const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + i); return uint4{v.x, v.y, v.z, v.w}; }
+        return src[i];
+    };
+    auto use = [&](const uint4& v) {
+        if (MODE == 0) { acc ^= v.x ^ v.y ^ v.z ^ v.w; return; }
+        __hip_atomic_fetch_add(&my[(v.x >> start_bit) & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&my[(v.y >> start_bit) & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&my[(v.z >> start_bit) & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&my[(v.w >> start_bit) & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    uint32_t i = begin + tid;
+    if (i + (U - 1) * 256 < end) {
+        uint4 a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = ld(i + u * 256);
+        i += U * 256;
+        for (; i + (U - 1) * 256 < end; i += U * 256) {
+            uint4 b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) b[u] = ld(i + u * 256);
+#pragma unroll
+            for (int u = 0; u < U; ++u) use(a[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) a[u] = b[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) use(a[u]);
+    }
+    for (; i < end; i += 256) use(ld(i));
+    __syncthreads();
+    if (MODE == 0) { if (acc == 0x9e3779b9u) table[0] = acc; return; }
+    table[(size_t)blockIdx.x * 256 + tid] = hist[tid] + hist[256 + tid] + hist[512 + tid] + hist[768 + tid];
+}
+
 struct Timer {
     struct Rec { std::string name; hipEvent_t e0, e1; };
     std::vector<Rec> recs;
@@ -222,6 +273,24 @@ int main(int argc, char** argv)
                            fault, seg_cnt, stride_b, mode, mode + kDynLowBits, (uint32_t*)nullptr, (const uint32_t*)nullptr,
                            (const uint32_t*)nullptr, 8u);
     };
+    if (strstr(only, "hist")) {
+        uint32_t* table;
+        CK(hipMalloc(&table, (size_t)8192 * 256 * 4));
+        for (int i = 0; i < NB; ++i) CK(hipMemcpyAsync(kbuf[i], orig, n * 4, hipMemcpyDeviceToDevice, 0));
+        int turn = 0;
+        auto bench_hist = [&](const char* name, auto&& launch) {
+            for (int it = 0; it < iters + 3; ++it) T.run(name, it >= 3, [&] { launch(kbuf[(turn++) % NB]); });
+        };
+        auto libk = radix_count_kernel<uint32_t, 8, 256>;
+        bench_hist("lib_count_2048", [&](E* k) { hipLaunchKernelGGL(libk, dim3(2048), dim3(256), 0, 0, (const E*)k, table, (uint32_t)n, 2048, 24, 32768u, 0); });
+#define HV(MODE_, NTL_, U_, G_)                                                                                                  \
+        bench_hist("m" #MODE_ "_nt" #NTL_ "_u" #U_ "_g" #G_, [&](E* k) {                                                         \
+            hipLaunchKernelGGL((hist_variant_kernel<MODE_, NTL_, U_>), dim3(G_), dim3(256), 0, 0, (const uint4*)k, (uint32_t)(n / 4), table, 24); });
+        HV(0, false, 4, 2048) HV(0, true, 4, 2048) HV(0, true, 8, 2048) HV(0, true, 4, 4096) HV(0, true, 8, 1024) HV(0, true, 2, 4096)
+        HV(1, false, 4, 2048) HV(1, true, 4, 2048) HV(1, true, 8, 2048) HV(1, true, 4, 4096) HV(1, true, 8, 1024) HV(1, true, 2, 4096)
+        T.report("hist 64Mi u32 (256 MiB read per launch; cold buffers in turns)");
+        return 0;
+    }
     chain("old/old/old", p1_old, p2_old, f_old);
 
 #define PERSIST(NT_, K_, WGS_, L1, S1, L2, S2, FIN)                                                                              \
