@@ -57,11 +57,20 @@ public:
     // RadixSortKeyValueKernels.cl:354-509): ascending by key, stable, values follow their keys
     void radixSort(const adl::Device* device, const adl::Buffer<u32>& keys, const adl::Buffer<u32>& values, int n,
                    int sortBits = 32);
+    // the same with 64-bit values and / or 64-bit keys: {32 key bits, index} pairs are sorted, keys and values
+    // gathered once at the end (adlhip_radix_sort_soa)
+    void radixSort(const adl::Device* device, const adl::Buffer<u32>& keys, const adl::Buffer<u64>& values, int n,
+                   int sortBits = 32);
+    void radixSort(const adl::Device* device, const adl::Buffer<u64>& keys, const adl::Buffer<u32>& values, int n,
+                   int sortBits = 64);
+    void radixSort(const adl::Device* device, const adl::Buffer<u64>& keys, const adl::Buffer<u64>& values, int n,
+                   int sortBits = 64);
 
 private:
     // device scratch owned by the object and grown lazily (reference: m_u32WorkBuffer[0] = ping-pong data,
     // m_u32WorkBuffer[1] = histogram table; Pprims.h:44-45)
     void reserve(const adl::Device* device, size_t tmpBytes, size_t workBytes);
+    void sortSoaWide(const adl::Device* device, void* keys, int keyBytes, void* values, int valueBytes, int n, int sortBits);
     adl::Buffer<unsigned char>* m_tmp;
     adl::Buffer<unsigned char>* m_work;
     bool m_cacheKernel;

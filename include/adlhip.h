@@ -181,6 +181,19 @@ int adlhip_radix_sort_soa32(adlhip_device* dev, uint32_t* d_keys_inout, uint32_t
                             uint32_t* d_tmp_keys, uint32_t* d_tmp_vals, void* d_work, size_t work_bytes,
                             size_t n, int sort_bits);
 
+/* The same on keys of 4 or 8 bytes and values of 4, 8 or 16 bytes ("SoA key/value API ... and 64-bit values";
+ * the reference's kernel, RadixSortKeyValueKernels.cl:354-509, takes `const u32* gSrc, const int* gSrcVal`).  Ascending by the
+ * low sort_bits key bits (a multiple of 4 in [4, 8 * key_bytes]), stable, values follow their keys; n < 2^32.
+ * (4, 4) is adlhip_radix_sort_soa32.  Every other width sorts {32 key bits, source index} pairs with the stable pair sort of
+ * adlhip_radix_sort_kv32 -- once for u32 keys, twice (low dword, then high dword) for u64 keys on more than 32 bits -- and
+ * fetches keys and values ONCE, at the end, from where the indices point; the value's width only costs in that gather.
+ * d_tmp_keys: n keys (may be NULL for 4-byte keys), d_tmp_vals: n values; sizes and the work buffer's size from
+ * adlhip_radix_sort_soa_scratch_bytes.  All buffers 16-byte aligned. */
+int adlhip_radix_sort_soa_scratch_bytes(adlhip_device* dev, int key_bytes, int value_bytes, size_t n, int sort_bits,
+                                        size_t* tmp_keys_bytes, size_t* tmp_vals_bytes, size_t* work_bytes);
+int adlhip_radix_sort_soa(adlhip_device* dev, void* d_keys_inout, int key_bytes, void* d_vals_inout, int value_bytes,
+                          void* d_tmp_keys, void* d_tmp_vals, void* d_work, size_t work_bytes, size_t n, int sort_bits);
+
 /* 64-bit keys, ascending; sort_bits multiple of 4 in [4,64]. */
 int adlhip_radix_sort_u64(adlhip_device* dev, uint64_t* d_keys_inout, uint64_t* d_tmp,
                           void* d_work, size_t work_bytes, size_t n, int sort_bits);

@@ -62,6 +62,8 @@ SIGNATURES = {
     "adlhip_radix_sort_kv32": (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
     "adlhip_radix_sort_soa32": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
     "adlhip_radix_sort_u64": (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _I]),
+    "adlhip_radix_sort_soa_scratch_bytes": (_I, [_VP, _I, _I, _SZ, _I, c_size_p, c_size_p, c_size_p]),
+    "adlhip_radix_sort_soa": (_I, [_VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _SZ, _SZ, _I]),
     "adlhip_segment_sort": (_I, [_VP, _I, _VP, _VP, _SZ, _SZ, _I]),
     "adlhip_scan_scratch_bytes": (_I, [_VP, _SZ, c_size_p]),
     "adlhip_exclusive_scan_u32": (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _VP]),

@@ -21,9 +21,9 @@
 #include "radix_kernels.hpp"
 #include "onesweep_kernels.hpp"
 #include "hybrid_kernels.hpp"
-#include "dict_kernels.hpp"
 #include "persist_kernels.hpp"
 #include "finish16_kernels.hpp"
+#include "soa_wide_kernels.hpp"
 
 namespace {
 
@@ -96,13 +96,9 @@ struct adlhip_device {
                               // (1: u64 keys, 2: u32 keys too, 0: the wave-per-segment LSD finish)
     int persist = 1;          // "sort.persist": the cursor passes of the large sort as persistent, prefetching kernels + the 16-bit finish
     int msd2_path = 1;        // "sort.msd2": the large sort (msd2_sort for keys, msd2s_sort for pairs); 2 = forced (tests)
-    int msd2_skip = 0, msd2_backoff = 32;   // sorts the next overflow report keeps off the large sort (x8 each time, reset by a success)
-    bool msd2_trusted = false;              // a good report has come in since the last bad one (msd2_decide)
-    bool msd2_waited = false;               // the handle's first probe has been waited for (msd2_first_verdict)
-    bool msd2_probe_pending = false;        // a sort did not fit: the next eligible sort lets the probe look at the keys again
-    bool dict_hint = false;                 // the last report said "few distinct values": whole-key sorts of keys go to the counting sort
-    int dict_path = 1;                      // "sort.dict": counting sort for keys that take at most 256 values (dict_kernels.hpp); 0 = off
-    adlhip::DictBlock* d_dict = nullptr;    // its dictionary and counters (handle-owned, counters zero between sorts)
+    int dict_path = 1;                      // "sort.dict": the large sort's safety net first tries the counting sort for keys that take at most
+                                            // 256 values (dict_kernels.hpp); 0 = off
+    adlhip::DictBlock* d_dict = nullptr;    // its dictionary and counters (handle-owned; rebuilt by every net that uses them)
     uint32_t* d_msd2 = nullptr;   // the large sort's handle-owned words, allocated with the handle and idle between sorts: cursors of
                                   // pass 1 (256, one 128-byte line each) and pass 2 (65536), overflow flag, done counter, the safety
                                   // net's barrier counter, the four sample words
@@ -1036,6 +1032,15 @@ uint32_t msd2_seg_shift(size_t n, bool bin_finish)
 // density varies by more than ~10 % over the key range go to the safety net (and, by the handle's hints, to the one-sweep passes)
 constexpr int kFullHeadroomPct = 50, kLeanHeadroomPct = 12;
 
+// Workgroups of the kernels that host the safety net (512 threads, one tile of the one-sweep pass's size in LDS: two per CU).
+// All of them must be resident at once -- the net's phases are separated by grid-wide barriers -- and the first 256 serve the
+// 256 buckets in the kernel's ordinary role.
+constexpr uint32_t kNetWgsMax = 512;
+constexpr size_t kNetTableBytes = (size_t)256 * kNetWgsMax * 4 + 1024;   // [256][workgroups] digit table + 256 totals
+uint32_t net_wgs(const adlhip_device* d) { return d->resident_wgs >= (int)kNetWgsMax ? kNetWgsMax : 256u; }
+// two handle-owned counters: nets run, and of those, sorted by counting (net_sort; "stat.net_runs" / "stat.net_counting")
+uint32_t* net_stats(const adlhip_device* d) { return d->d_msd2 + 8192 + 65536 + 16; }
+
 Msd2Layout msd2_layout(size_t n, size_t elem_bytes, int headroom_pct = kFullHeadroomPct)
 {
     Msd2Layout L;
@@ -1056,114 +1061,13 @@ Msd2Layout msd2_layout(size_t n, size_t elem_bytes, int headroom_pct = kFullHead
     L.off_off = L.off_cnt + 65536 * 4;
     L.off_hard = align_up(L.off_off + 65537 * 4, 256);                       // segments the binning finish hands to the LSD finish
     L.off_coop = L.off_hard + 65536 * 4;                                     // safety net: table [256][256] + 256 totals
-    L.off_slab_a = align_up(L.off_coop + (size_t)256 * 256 * 4 + 1024, 256);
+    L.off_slab_a = align_up(L.off_coop + kNetTableBytes, 256);
     L.off_slab_b = align_up(L.off_slab_a + (size_t)256 * L.stride_a * elem_bytes, 256);
     // u32 keys: 16-bit second slab (when the finish has 16 bits to sort: w = 8)
     const size_t slab_b_bytes = (size_t)L.slots * L.stride_b * (elem_bytes == 4 && L.seg_shift == 8 ? 2 : elem_bytes);
     L.slab_b_in_tmp = elem_bytes == 4 && L.seg_shift == 8 && n >= kSlabInTmpMin && slab_b_bytes <= n * elem_bytes;
     L.total = L.off_slab_b + (L.slab_b_in_tmp ? 0 : slab_b_bytes);
     return L;
-}
-
-// Host-side policy.  The kernels report into pinned memory what happened (1 = the keys fitted the slabs, 2 = they did not);
-// the host reads that word at the next call, without synchronising.
-//   * a handle that has no good report yet -- a fresh one, or one whose back-off has just run out -- does not risk the safety
-//     net (2.8 ms at 64 Mi keys): the sort takes the per-digit passes and msd2_probe_kernel rides along (~20 us), which says
-//     whether the keys' first digit would fit;
-//   * after a good report the handle uses the large sort;
-//   * after a bad one (from the probe or from a sort that went through its safety net) the next 32 (256, 2048, 4096)
-//     eligible sorts go straight to the per-digit passes, then the probe looks again.
-// Only speed depends on any of it ("sort.msd2" = 2 forces the path, 0 = off).
-enum Msd2Choice { kMsd2Skip = 0, kMsd2Use = 1, kMsd2Probe = 2, kMsd2Dict = 3 };
-Msd2Choice msd2_decide(adlhip_device* d)
-{
-    if (d->msd2_path >= 2) return kMsd2Use;
-    const uint32_t report = d->h_fault[11];
-    d->h_fault[11] = 0u;
-    if (report == 4u) {          // few distinct values (the probe, or a counting sort that went through)
-        d->dict_hint = true;
-        d->msd2_skip = 0;
-    } else if (report == 2u) {   // the keys did not fit (probe, large sort or counting sort)
-        d->msd2_trusted = false;
-        d->dict_hint = false;
-        d->msd2_skip = d->msd2_backoff;
-        d->msd2_backoff = std::min(d->msd2_backoff * 8, 4096);
-        d->msd2_probe_pending = true;   // the next sort takes the per-digit passes and lets the probe say what the keys are like now
-    } else if (report == 1u) {   // a large sort went through
-        d->msd2_trusted = true;
-        d->dict_hint = false;
-        d->msd2_backoff = 32;
-    } else if (report == 3u) {   // the probe saw no obstacle: try the sort, but keep the back-off where it is -- keys that pass the
-        d->msd2_trusted = true;  // probe and still overflow (skew at the scale of single segments) must not cycle for ever
-        d->dict_hint = false;
-    }
-    if (d->dict_hint) return kMsd2Dict;
-    if (d->msd2_skip > 0) {
-        --d->msd2_skip;
-        if (d->msd2_probe_pending) {
-            d->msd2_probe_pending = false;
-            return kMsd2Probe;
-        }
-        return kMsd2Skip;
-    }
-    return d->msd2_trusted ? kMsd2Use : kMsd2Probe;
-}
-
-// A handle's FIRST eligible sort waits for the probe's verdict (one stream synchronisation per handle: its first large sort
-// allocates the handle-owned words anyway) and takes the large sort at once when the keys fit -- round 2 sent every first sort
-// down the per-digit passes and let the verdict arrive later (0.78-0.86 ms for the first 64 Mi keys, whatever they were).  Later
-// probes (after a back-off) ride along unsynchronised as before.
-Msd2Choice msd2_first_verdict(adlhip_device* d)
-{
-    if (d->msd2_waited) return kMsd2Probe;   // not the first time: the verdict arrives with a later call
-    d->msd2_waited = true;
-    if (hipStreamSynchronize(d->stream) != hipSuccess) return kMsd2Probe;
-    const Msd2Choice c = msd2_decide(d);
-    return c == kMsd2Use || c == kMsd2Dict ? c : kMsd2Skip;
-}
-
-// elem_bytes / key_bits of the array the keys are read from (AoS pairs: 8 / 32, the key is the low dword)
-// dict: also try to build the counting sort's dictionary (whole-key sorts of keys only)
-int msd2_probe(adlhip_device* d, const void* keys, size_t elem_bytes, int key_bits, size_t n, bool dict = false)
-{
-    adlhip::DictBlock* blk = dict ? d->d_dict : nullptr;
-    // repeats among the 16 Ki samples beyond which some value would outgrow a segment slab: D distinct values, each with n / D copies,
-    // fit while D >= the number of segments (a slab holds 1.5 x the mean); S samples of D values repeat S - D (1 - e^(-S/D)) times
-    // (taken at 3/4 of that: n / D = 1.33 x the mean still fits)
-    const double S = 16384.0, D = 0.75 * (double)(256u << msd2_seg_shift(n, false));
-    const uint32_t dup_limit = (uint32_t)(S - D * (1.0 - std::exp(-S / D)) + 600.0);   // + the table's own collisions (~500) and noise
-    return launch(d, "msd2_probe", [&] {
-        if (elem_bytes == 4)
-            hipLaunchKernelGGL(adlhip::msd2_probe_kernel<uint32_t>, dim3(1), dim3(1024), 0, d->stream, (const uint32_t*)keys, (uint32_t)n,
-                               key_bits, d->h_fault + 11, blk, dup_limit);
-        else
-            hipLaunchKernelGGL(adlhip::msd2_probe_kernel<uint64_t>, dim3(1), dim3(1024), 0, d->stream, (const uint64_t*)keys, (uint32_t)n,
-                               key_bits, d->h_fault + 11, blk, dup_limit);
-    });
-}
-
-// Counting sort of keys that take few distinct values (dict_kernels.hpp): probe (builds the dictionary from 16 Ki sampled keys) ->
-// count (every key looked up) -> fill (the runs, in place) -- or, when a key is not in the dictionary, the cooperative LSD sort
-// inside the fill kernel.  64 Mi keys: ~0.15 ms where the one-sweep path takes 0.60-0.65 (profiles/r3_distributions.txt).
-template <typename E>
-int dict_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n)
-{
-    int rc = msd2_probe(d, data, sizeof(E), 8 * (int)sizeof(E), n, true);
-    if (rc) return rc;
-    constexpr size_t VEC = 16 / sizeof(E);
-    const uint32_t wgs_c = (uint32_t)std::min<size_t>(adlhip::kDictWGs, (n / VEC + adlhip::kDictNT - 1) / adlhip::kDictNT);
-    rc = launch(d, sizeof(E) == 4 ? "dict_count_u32" : "dict_count_u64", [&] {
-        hipLaunchKernelGGL(adlhip::dict_count_kernel<E>, dim3(std::max(1u, wgs_c)), dim3(adlhip::kDictNT), 0, d->stream, (const E*)data,
-                           (uint32_t)n, d->d_dict);
-    });
-    if (rc) return rc;
-    using CC = adlhip::TileCfg<E, 8, adlhip::kDictNT, 16>;   // the safety net's tile
-    const uint32_t chunk = 32768;
-    const uint32_t wgs_f = (uint32_t)std::max<size_t>(256, (n + chunk - 1) / chunk);
-    return launch(d, sizeof(E) == 4 ? "dict_fill_u32" : "dict_fill_u64", [&] {
-        hipLaunchKernelGGL(adlhip::dict_fill_kernel<E>, dim3(wgs_f), dim3(adlhip::kDictNT), CC::LDS_BYTES, d->stream, data, tmp, (uint32_t)n,
-                           d->d_dict, reinterpret_cast<uint32_t*>(work), d->d_fault, d->h_fault + 11, 8 * (int)sizeof(E), chunk);
-    });
 }
 
 template <typename E, typename S, bool SOA = false>
@@ -1250,11 +1154,13 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int headr
     // the untouched input with the cooperative LSD sort (hybrid_kernels.hpp coop_lsd_sort); the finish then returns at once
     uint32_t* bar = done + 1;
     uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
-    using CC = adlhip::TileCfg<E, 8, 256, 16>;
+    using CC = adlhip::TileCfg<E, 8, 512, K>;   // the net's tile: the one-sweep pass's own (16 Ki keys / 8 Ki 8-byte elements)
+    auto ko = adlhip::msd2_offsets_kernel<E, 512, K>;
+    if (ensure_lds(ko, CC::LDS_BYTES)) return ADLHIP_FAILURE;
     rc = launch(d, "msd2_offsets", [&] {
-        hipLaunchKernelGGL(adlhip::msd2_offsets_kernel<E>, dim3(256), dim3(256), CC::LDS_BYTES, d->stream, cur_a, cur_b, flag, done, bar,
-                           seg_cnt, seg_off, mode, d->h_fault + 11, (uint32_t)n, sample, data, tmp, ctable, d->d_fault, KEY_BITS,
-                           8u - L.seg_shift);
+        hipLaunchKernelGGL(ko, dim3(net_wgs(d)), dim3(512), CC::LDS_BYTES, d->stream, cur_a, cur_b, flag, done, bar,
+                           seg_cnt, seg_off, mode, (uint32_t)n, sample, data, tmp, ctable, d->d_fault, KEY_BITS,
+                           8u - L.seg_shift, d->dict_path ? d->d_dict : nullptr, net_stats(d));
     });
     if (rc) return rc;
     // the finish sorts the bits below the second digit (the offsets kernel has published how many)
@@ -1326,7 +1232,7 @@ Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8, bool slab16 = false)
     L.off_off = L.off_cnt + 65536 * 4;
     L.off_hard = align_up(L.off_off + 65537 * 4, 256);
     L.off_coop = L.off_hard + 65536 * 4;
-    L.off_tickets = align_up(L.off_coop + (size_t)256 * 256 * 4 + 1024, 256);
+    L.off_tickets = align_up(L.off_coop + kNetTableBytes, 256);
     // the regions are sized by bounds that do not depend on `pieces` and grow with n, so that the scratch for n suffices
     // for every smaller n (adlhip_radix_sort_scratch_bytes): sub-slabs of a bucket together <= n/256 + 16 * (head-room),
     // rows of pass A <= n/tile + 16, rows of a bucket in pass B <= its sub-slabs / tile + 16
@@ -1566,12 +1472,18 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
         if (rc) return rc;
     }
     uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
-    using CC = adlhip::TileCfg<E, 8, 256, 16>;   // the safety net's tile (it runs in the offsets kernel when a run did not fit)
+    constexpr int NK = sizeof(E) == 4 ? 32 : 16;
+    // whole-key sorts of keys: equal keys are interchangeable, the net may sort them by counting (dict_kernels.hpp)
+    adlhip::DictBlock* net_dict = (k32 || KEY64) && whole && !soa_keys && d->dict_path ? d->d_dict : nullptr;
+    using CC = adlhip::TileCfg<E, 8, 512, NK>;   // the safety net's tile (it runs in the offsets kernel when a run did not fit)
+    auto ko = adlhip::msd2s_offsets_kernel<E, CT::TILE, 512, NK>;
+    if (ensure_lds(ko, CC::LDS_BYTES)) return ADLHIP_FAILURE;
     rc = launch(d, "msd2s_offsets", [&] {
-        hipLaunchKernelGGL((adlhip::msd2s_offsets_kernel<E, CT::TILE>), dim3(256), dim3(256), CC::LDS_BYTES, d->stream,
+        hipLaunchKernelGGL(ko, dim3(net_wgs(d)), dim3(512), CC::LDS_BYTES, d->stream,
                            (const uint32_t*)status_a, L.rows_a, L.slice, L.pieces, (const uint32_t*)status_b, L.rows_b, L.stride_a, flag,
-                           done, bar, seg_cnt, seg_off, mode, d->h_fault + 11, (uint32_t)n, (const adlhip::StablePlace*)place,
-                           soa_keys ? slab_a : data, soa_keys ? slab_b : tmp, ctable, d->d_fault, soa_keys, soa_vals, cur_b, 8u - L.seg_shift);
+                           done, bar, seg_cnt, seg_off, mode, (uint32_t)n, (const adlhip::StablePlace*)place,
+                           soa_keys ? slab_a : data, soa_keys ? slab_b : tmp, ctable, d->d_fault, soa_keys, soa_vals, cur_b, 8u - L.seg_shift,
+                           net_dict, net_stats(d));
     });
     if (rc) return rc;
     const int low_max = sort_bits - 8 - (int)L.seg_shift;
@@ -1726,28 +1638,18 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
             form = kLargeNone;
         }
     }
+    // The large sort takes every input it is eligible for by size, bits and scratch -- whatever the keys are like: runs that do not fit
+    // their slabs are detected on the device and the sort's own offsets kernel then sorts the untouched input (net_sort: counting
+    // sort for few distinct values, else LSD passes with grid barriers).  Nothing is reported to the host and nothing is remembered:
+    // a handle's first sort of an input takes the time its hundredth does.
     if (form != kLargeNone) {
-        // the counting sort for few distinct values: whole keys (equal keys are interchangeable), the safety net's 256 workgroups
-        const bool dict_ok = keys && sort_bits == max_bits && d->dict_path && n > kMsd2AutoMin && n < (size_t(1) << 32) &&
-                             work_bytes >= (size_t)256 * 256 * 4 + 1024;
-        Msd2Choice c = msd2_decide(d);
-        if (c == kMsd2Probe) {
-            if (msd2_probe(d, data, sizeof(E), sort_bits, n, dict_ok)) return ADLHIP_FAILURE;
-            c = msd2_first_verdict(d);
-        }
-        if (c == kMsd2Dict) {
-            if (dict_ok) return dict_sort<E>(d, data, tmp, work, n);
-            c = kMsd2Skip;   // (a hint from a sort of another kind: pairs and partial sorts keep their paths)
-        }
-        if (c == kMsd2Use) {
-            if (form == kLargeCursor) return msd2_sort<E>(d, data, tmp, work, n, headroom);
-            const bool hybrid = form == kLargeHybrid;
-            if constexpr (sizeof(E) == 4) {
-                return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits, nullptr, nullptr, hybrid);
-            } else {
-                if (keys) return msd2s_sort<E, true>(d, data, tmp, work, n, sort_bits, nullptr, nullptr, hybrid);
-                return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits);
-            }
+        if (form == kLargeCursor) return msd2_sort<E>(d, data, tmp, work, n, headroom);
+        const bool hybrid = form == kLargeHybrid;
+        if constexpr (sizeof(E) == 4) {
+            return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits, nullptr, nullptr, hybrid);
+        } else {
+            if (keys) return msd2s_sort<E, true>(d, data, tmp, work, n, sort_bits, nullptr, nullptr, hybrid);
+            return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits);
         }
     }
     return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, work_bytes, n, plan);
@@ -1821,6 +1723,76 @@ int partition_top_byte_entry(adlhip_device* d, const E* in, E* out, uint32_t* to
     int rc = partition_top_byte<E>(d, in, out, work, work_bytes, n, &totals);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(totals256, totals, 256 * 4, hipMemcpyDeviceToDevice, d->stream));
+    return ADLHIP_SUCCESS;
+}
+
+// ---- SoA key-value sort with 4- / 8-byte keys and 4- / 8- / 16-byte values (soa_wide_kernels.hpp) -----------------------------
+struct SoaWideLayout {
+    size_t off_pairs_a, off_pairs_b, off_kv, kv_bytes, total;
+};
+SoaWideLayout soa_wide_layout(const adlhip_device* d, size_t n)
+{
+    SoaWideLayout L;
+    L.off_pairs_a = 0;
+    L.off_pairs_b = align_up(n * 8, 256);
+    L.off_kv = 2 * L.off_pairs_b;
+    L.kv_bytes = sort_work_bytes(d, ADLHIP_ELEM_KV32, n, 32, 1);   // (whole keys need the least of the large sort's forms; partial
+    L.kv_bytes = std::max(L.kv_bytes, sort_work_bytes(d, ADLHIP_ELEM_KV32, n, 28, 1));   // sorts the most: size for either)
+    L.total = L.off_kv + L.kv_bytes;
+    return L;
+}
+
+struct V16 {
+    uint32_t x, y, z, w;
+} __attribute__((aligned(16)));
+
+template <typename K, typename V>
+int soa_wide_sort(adlhip_device* d, K* keys, V* vals, K* tmp_keys, V* tmp_vals, void* work, size_t n, int sort_bits)
+{
+    const SoaWideLayout L = soa_wide_layout(d, n);
+    char* w = static_cast<char*>(work);
+    uint64_t* pa = reinterpret_cast<uint64_t*>(w + L.off_pairs_a);
+    uint64_t* pb = reinterpret_cast<uint64_t*>(w + L.off_pairs_b);
+    void* kv = w + L.off_kv;
+    const uint32_t nn = (uint32_t)n;
+    const uint32_t wgs = (uint32_t)std::min<size_t>((n + adlhip::kSoaNT - 1) / adlhip::kSoaNT, (size_t)d->prop.multiProcessorCount * 16);
+    int rc = launch(d, sizeof(K) == 4 ? "soa_pack_index_k32" : "soa_pack_index_k64", [&] {
+        hipLaunchKernelGGL(adlhip::soa_pack_index_kernel<K>, dim3(wgs), dim3(adlhip::kSoaNT), 0, d->stream, (const K*)keys, pa, nn);
+    });
+    if (rc) return rc;
+    // the stable pair sort of Pprims::radixSort(Buffer<uint2>) (Pprims.h:38) on {low key dword, index}
+    rc = sort_entry<uint64_t>(d, ADLHIP_ELEM_KV32, pa, pb, kv, L.kv_bytes, n, std::min(sort_bits, 32), 32);
+    if (rc) return rc;
+    const uint64_t* sorted = pa;
+    if constexpr (sizeof(K) == 8) {
+        if (sort_bits > 32) {   // second 32-bit digit; the sort is stable, so equal high dwords keep the order of their low dwords
+            rc = launch(d, "soa_repack_high", [&] {
+                hipLaunchKernelGGL(adlhip::soa_repack_high_kernel, dim3(wgs), dim3(adlhip::kSoaNT), 0, d->stream, (const uint64_t*)keys,
+                                   (const uint64_t*)pa, pb, nn);
+            });
+            if (rc) return rc;
+            rc = sort_entry<uint64_t>(d, ADLHIP_ELEM_KV32, pb, pa, kv, L.kv_bytes, n, sort_bits - 32, 32);
+            if (rc) return rc;
+            sorted = pb;
+        }
+    }
+    // u32 keys are the pairs' own low dwords and go straight to the caller's array; everything that is gathered lands in the
+    // partner arrays first (the gather reads its source out of order) and is copied back (Pprims.cpp:298-301 copies back too)
+    K* kout = sizeof(K) == 4 ? keys : tmp_keys;
+    rc = launch(d, "soa_gather", [&] {
+        hipLaunchKernelGGL((adlhip::soa_gather_kernel<K, V>), dim3(wgs), dim3(adlhip::kSoaNT), 0, d->stream, sorted, (const K*)keys, kout,
+                           (const V*)vals, tmp_vals, nn);
+    });
+    if (rc) return rc;
+    if (sizeof(K) == 8) HIPCHK(hipMemcpyAsync(keys, tmp_keys, n * sizeof(K), hipMemcpyDeviceToDevice, d->stream));
+    HIPCHK(hipMemcpyAsync(vals, tmp_vals, n * sizeof(V), hipMemcpyDeviceToDevice, d->stream));
+    return ADLHIP_SUCCESS;
+}
+
+int soa_check_widths(int key_bytes, int value_bytes)
+{
+    if (key_bytes != 4 && key_bytes != 8) return fail("key_bytes must be 4 or 8, got %d", key_bytes);
+    if (value_bytes != 4 && value_bytes != 8 && value_bytes != 16) return fail("value_bytes must be 4, 8 or 16, got %d", value_bytes);
     return ADLHIP_SUCCESS;
 }
 
@@ -1970,13 +1942,13 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         // workgroups each) this device keeps resident at once: asked of the runtime for the two largest of them
         int a = 0, b = 0;
         using CS = adlhip::TileCfg<uint32_t, 8, 512, 32>;
-        using CO = adlhip::TileCfg<uint64_t, 8, 256, 16>;
+        using CO = adlhip::TileCfg<uint64_t, 8, 512, 16>;
         const size_t lds_s = std::max<size_t>(sizeof(uint32_t) * 512 * 32 + (size_t)8 * 256 * 6 + 64, CS::LDS_BYTES);
         auto ks = adlhip::segment_sort_kernel<uint32_t, 512, 32, 8>;
-        auto ko = adlhip::msd2_offsets_kernel<uint64_t>;
-        if (ensure_lds(ks, lds_s) == ADLHIP_SUCCESS &&
+        auto ko = adlhip::msd2_offsets_kernel<uint64_t, 512, 16>;
+        if (ensure_lds(ks, lds_s) == ADLHIP_SUCCESS && ensure_lds(ko, CO::LDS_BYTES) == ADLHIP_SUCCESS &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(ks), 512, lds_s) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(ko), 256, CO::LDS_BYTES) == hipSuccess)
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(ko), 512, CO::LDS_BYTES) == hipSuccess)
             d->resident_wgs = std::min(a, b) * d->prop.multiProcessorCount;
         else
             d->resident_wgs = d->prop.multiProcessorCount;   // one per CU at least
@@ -2305,16 +2277,53 @@ int adlhip_radix_sort_soa32(adlhip_device* d, uint32_t* keys, uint32_t* vals, ui
     if (!vals || !tmp_vals) return fail("null value buffer passed to radix sort");
     if ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(tmp_vals)) & 15u)
         return fail("sort buffers must be 16-byte aligned");
-    if (large_sort_form(d, 8, false, n, sort_bits, 32) != kLargeNone && large_work_bytes(kLargeStable, 8, n, sort_bits == 32) <= work_bytes) {
-        Msd2Choice c = msd2_decide(d);
-        if (c == kMsd2Probe) {
-            if (msd2_probe(d, keys, 4, sort_bits, n)) return ADLHIP_FAILURE;
-            c = msd2_first_verdict(d);
-        }
-        if (c == kMsd2Use) return msd2s_sort<uint64_t, false>(d, nullptr, nullptr, work, n, sort_bits, keys, vals);   // (kMsd2Dict: keys only)
-    }
+    if (large_sort_form(d, 8, false, n, sort_bits, 32) != kLargeNone && large_work_bytes(kLargeStable, 8, n, sort_bits == 32) <= work_bytes)
+        return msd2s_sort<uint64_t, false>(d, nullptr, nullptr, work, n, sort_bits, keys, vals);
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
     return run_sort<SoaBuf>(d, SoaBuf{keys, vals}, SoaBuf{tmp_keys, tmp_vals}, work, work_bytes, n, plan);
+}
+
+int adlhip_radix_sort_soa_scratch_bytes(adlhip_device* d, int key_bytes, int value_bytes, size_t n, int sort_bits, size_t* tmp_keys_bytes,
+                                        size_t* tmp_vals_bytes, size_t* work_bytes)
+{
+    if (!d) return fail("null device handle");
+    if (soa_check_widths(key_bytes, value_bytes)) return ADLHIP_FAILURE;
+    if (sort_bits < 4 || sort_bits > 8 * key_bytes || (sort_bits & 3)) return fail("sort_bits must be a multiple of 4 in [4,%d], got %d", 8 * key_bytes, sort_bits);
+    if (tmp_keys_bytes) *tmp_keys_bytes = align_up(n * (size_t)key_bytes, 256);
+    if (tmp_vals_bytes) *tmp_vals_bytes = align_up(n * (size_t)value_bytes, 256);
+    if (work_bytes) {
+        if (key_bytes == 4 && value_bytes == 4) *work_bytes = sort_work_bytes(d, ADLHIP_ELEM_SOA32, n, sort_bits, 1);
+        else *work_bytes = soa_wide_layout(d, n).total;
+    }
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_radix_sort_soa(adlhip_device* d, void* keys, int key_bytes, void* vals, int value_bytes, void* tmp_keys, void* tmp_vals,
+                          void* work, size_t work_bytes, size_t n, int sort_bits)
+{
+    if (soa_check_widths(key_bytes, value_bytes)) return ADLHIP_FAILURE;
+    if (key_bytes == 4 && value_bytes == 4)
+        return adlhip_radix_sort_soa32(d, (uint32_t*)keys, (uint32_t*)vals, (uint32_t*)tmp_keys, (uint32_t*)tmp_vals, work, work_bytes, n, sort_bits);
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (sort_bits < 4 || sort_bits > 8 * key_bytes || (sort_bits & 3))   // Pprims.cpp:330
+        return fail("sort_bits must be a multiple of 4 in [4,%d], got %d", 8 * key_bytes, sort_bits);
+    if (n > kMaxElems || n >= (size_t(1) << 32)) return fail("n = %zu exceeds the supported maximum", n);
+    if (n == 0) return ADLHIP_SUCCESS;
+    if (!keys || !vals || !tmp_vals || !work || (key_bytes == 8 && !tmp_keys)) return fail("null buffer passed to radix sort");
+    if ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(tmp_keys) |
+         reinterpret_cast<uintptr_t>(tmp_vals) | reinterpret_cast<uintptr_t>(work)) & 15u)
+        return fail("sort buffers must be 16-byte aligned");
+    const size_t need = soa_wide_layout(d, n).total;
+    if (work_bytes < need) return fail("work buffer too small: %zu < %zu (adlhip_radix_sort_soa_scratch_bytes)", work_bytes, need);
+#define ADLHIP_SOA(K_, V_) return soa_wide_sort<K_, V_>(d, (K_*)keys, (V_*)vals, (K_*)tmp_keys, (V_*)tmp_vals, work, n, sort_bits)
+    if (key_bytes == 4) {
+        if (value_bytes == 8) ADLHIP_SOA(uint32_t, uint64_t);
+        ADLHIP_SOA(uint32_t, V16);
+    }
+    if (value_bytes == 4) ADLHIP_SOA(uint64_t, uint32_t);
+    if (value_bytes == 8) ADLHIP_SOA(uint64_t, uint64_t);
+    ADLHIP_SOA(uint64_t, V16);
+#undef ADLHIP_SOA
 }
 
 int adlhip_segment_sort(adlhip_device* d, int elem_kind, void* data, const uint32_t* seg_start, size_t num_segments,
@@ -2458,7 +2467,6 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
     } else if (!strcmp(name, "sort.dict")) {
         if (value != 0 && value != 1) return fail("sort.dict must be 0 (off) or 1 (counting sort for keys that take few distinct values)");
         d->dict_path = value;
-        if (!value) d->dict_hint = false;
     } else if (!strcmp(name, "sort.binfinish")) {
         if (value < 0 || value > 2) return fail("sort.binfinish must be 0 (LSD finish), 1 (binning finish for whole u64 keys from 24 Mi keys up) or 2 (always, u32 keys too)");
         d->bin_finish = value;
@@ -2494,6 +2502,13 @@ int adlhip_get_param(adlhip_device* d, const char* name, int* value)
     else if (!strcmp(name, "sort.persist")) *value = d->persist;
     else if (!strcmp(name, "sort.dict")) *value = d->dict_path;
     else if (!strcmp(name, "debug.resident_wgs")) *value = d->resident_wgs;
+    else if (!strcmp(name, "stat.net_runs") || !strcmp(name, "stat.net_counting")) {
+        // how often the large sort's safety net has run on this handle, and how often it sorted by counting (waits for the stream)
+        uint32_t v[2] = {0u, 0u};
+        HIPCHK(hipMemcpyAsync(v, net_stats(d), 8, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        *value = (int)v[name[9] == 'c' ? 1 : 0];
+    }
     else if (!strcmp(name, "sort.lds_ordered")) *value = d->lds_ordered;
     else if (!strcmp(name, "profile")) *value = d->profile;
     else return fail("unknown parameter '%s'", name);

@@ -1,5 +1,5 @@
 // dict_build.hpp -- the dictionary of the counting sort for keys that take few distinct values (dict_kernels.hpp has the story):
-// its layout and the routine that builds it from sampled keys, here because the probe kernel of hybrid_kernels.hpp calls it.
+// its layout and the routine that builds it from sampled keys.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -13,13 +13,11 @@ constexpr unsigned long long kDictEmpty = ~0ull;
 struct DictBlock {                                  // handle-owned device memory
     uint32_t n_values;                              // 0: the sampled keys take more than kDictMax values (no dictionary)
     uint32_t miss;                                  // count kernel: some key is not in the dictionary
-    uint32_t done;                                  // count kernel: workgroups finished
-    uint32_t bar;                                   // the safety net's grid-barrier counter
+    uint32_t pad[2];
     unsigned long long value[kDictMax];             // ascending
     unsigned long long slot_key[kDictSlots];        // hash table: key (kDictEmpty = free) ...
     uint32_t slot_idx[kDictSlots];                  // ... -> its index in value[]
-    uint32_t count[kDictMax];                       // zero between sorts (the fill kernel's first workgroup clears them)
-    uint32_t offset[kDictMax + 1];                  // exclusive scan of count[], offset[n_values] = n
+    uint32_t count[kDictMax];                       // per value; cleared by the workgroup that builds the dictionary
 };
 
 __device__ __forceinline__ uint32_t dict_hash(unsigned long long v)
@@ -30,16 +28,17 @@ __device__ __forceinline__ uint32_t dict_hash(unsigned long long v)
     return (uint32_t)v & (uint32_t)(kDictSlots - 1);
 }
 
-// Built by ONE workgroup of 1024 threads from the keys it has sampled (called by the probe kernel).  smp[i] = the thread's
-// samples; all threads must call.  Returns the number of distinct values if they fit the dictionary, else 0.
-template <int PER_THREAD>
-__device__ __forceinline__ uint32_t dict_build(const unsigned long long (&smp)[PER_THREAD], DictBlock* __restrict__ blk)
+// Built by ONE workgroup of NT threads from the keys it has sampled.  smp[i] = the thread's samples (the all-ones key of the
+// sorted width arrives as kDictEmpty, see dict_sample_build); all threads must call.  smem: 18 KiB of the caller's dynamic LDS.
+// Returns the number of distinct values if they fit the dictionary, else 0.
+template <int PER_THREAD, int NT>
+__device__ __forceinline__ uint32_t dict_build(const unsigned long long (&smp)[PER_THREAD], DictBlock* __restrict__ blk, unsigned char* smem)
 {
-    __shared__ unsigned long long s_tab[2048];   // open addressing over the samples
-    __shared__ unsigned long long s_val[kDictMax];
+    unsigned long long* s_tab = reinterpret_cast<unsigned long long*>(smem);            // [2048] open addressing over the samples
+    unsigned long long* s_val = s_tab + 2048;                                            // [kDictMax]
     __shared__ uint32_t s_cnt, s_maxkey, s_n;
     const int tid = (int)threadIdx.x;
-    for (int i = tid; i < 2048; i += 1024) s_tab[i] = kDictEmpty;
+    for (int i = tid; i < 2048; i += NT) s_tab[i] = kDictEmpty;
     if (tid == 0) {
         s_cnt = 0u;
         s_maxkey = 0u;
@@ -73,23 +72,21 @@ __device__ __forceinline__ uint32_t dict_build(const unsigned long long (&smp)[P
     }
     __syncthreads();
     const uint32_t distinct = s_cnt + s_maxkey;
-    if (tid == 0) {   // whatever the samples say: the count kernel's flags and the safety net's barrier counter start from zero (a
-        blk->miss = 0u;   // net that ran before leaves the counter at a multiple of 256, and a barrier that starts there lets
-        blk->done = 0u;   // everyone through at once)
-        blk->bar = 0u;
-    }
+    // whatever the samples say: this sort's miss flag and counters start from zero
+    if (tid == 0) blk->miss = 0u;
+    for (int i = tid; i < kDictMax; i += NT) blk->count[i] = 0u;
     if (distinct == 0u || distinct > (uint32_t)kDictMax) {
         if (tid == 0) blk->n_values = 0u;
         return 0u;
     }
     // compact the values, then rank them (at most 256: every value counts the smaller ones)
-    for (int i = tid; i < 2048; i += 1024) {
+    for (int i = tid; i < 2048; i += NT) {
         const unsigned long long v = s_tab[i];
         if (v != kDictEmpty) s_val[atomicAdd(&s_n, 1u)] = v;
     }
     __syncthreads();
     if (tid == 0 && s_maxkey) s_val[s_n] = kDictEmpty;   // ranks last by itself
-    for (int i = tid; i < kDictSlots; i += 1024) {
+    for (int i = tid; i < kDictSlots; i += NT) {
         blk->slot_key[i] = kDictEmpty;
         blk->slot_idx[i] = 0u;
     }

@@ -2,31 +2,36 @@
 // keys) are sorted by counting: look every key up in a dictionary of the values, count, and write the runs.
 //
 // Why it exists.  Pprims::radixSort (Tahoe/ParallelPrimitives/Pprims.cpp:304-406) sorts such keys like any others: sortBits / 4
-// passes over the data.  The large sort of this back-end (hybrid_kernels.hpp) cannot take them at all -- it gives every bucket
-// and segment the same room, and a value with a million copies outgrows any slab -- so they used to fall to the one-sweep path:
-// 0.60-0.65 ms for 64 Mi keys that are all equal, take 16 values or differ in their low byte only.  Counting needs one read
-// and one write of the array: ~0.15 ms.  Equal keys are indistinguishable, so the output of a sort of whole keys is determined
-// by the counts alone; it is bit for bit what the reference's CPU sort (Tahoe/Algorithm/Sort/RadixSort.cpp:58-104) produces.
-// ({key, value} pairs and sorts on part of the key keep the ordinary paths: there equal keys are not interchangeable.)
+// passes over the data.  The large sort of this back-end (hybrid_kernels.hpp) gives every bucket and segment the same room, and a
+// value with a million copies outgrows any slab: such keys end in its safety net (net_sort, hybrid_kernels.hpp), whose ordinary
+// work is four LSD passes (about 1 ms for 64 Mi keys).  Counting needs one read and one write of the array.  Equal keys are
+// indistinguishable, so the output of a sort of whole keys is determined by the counts alone; it is bit for bit what the
+// reference's CPU sort (Tahoe/Algorithm/Sort/RadixSort.cpp:58-104) produces.  ({key, value} pairs and sorts on part of the key
+// go straight to the LSD passes: there equal keys are not interchangeable.)
 //
-//   1. large_probe_kernel (hybrid_kernels.hpp's probe, extended)  16 Ki sampled keys; if they take at most 256 values it writes
-//      the dictionary -- the values in ascending order and a 1024-slot hash table over them -- and says so to the host
-//   2. dict_count_kernel   every key is looked up (hash, one or two LDS reads) and counted; a key that is not in the dictionary
-//      raises `miss` (the sample cannot see a value that occurs once in a million).  The last workgroup scans the counts
-//   3. dict_fill_kernel    writes the runs in place -- unless `miss` is set: then the input is untouched and its first 256
-//      workgroups sort it with the cooperative LSD sort (hybrid_kernels.hpp coop_lsd_sort), the large sort's safety net
+// Round 4: the three steps are phases of the net itself, separated by its grid barriers (round 3: three launches chosen by a
+// host-side hint that a probe launch had left behind):
+//   1. dict_sample_build   workgroup 0 samples 16 Ki keys; if they take at most 256 values it writes the dictionary -- the values in
+//      ascending order and a 1024-slot hash table over them
+//   2. dict_count_range    every key is looked up (hash, one or two LDS reads) and counted; a key that is not in the dictionary
+//      raises `miss` (the sample cannot see a value that occurs once in a million) and the net goes on to its LSD passes
+//   3. dict_fill_range     every workgroup scans the counts itself and writes its share of the runs, in place
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "hybrid_kernels.hpp"
+#include "radix_kernels.hpp"
+#include "dict_build.hpp"
 
 namespace adlhip {
+
+__device__ __forceinline__ size_t probe_sample_index(uint32_t k, uint32_t n);   // hybrid_kernels.hpp
 
 // index of v in the dictionary, or 0xffffffff.  s_key / s_idx: the hash table in LDS; n_values for the all-ones key.
 // K = the key type of the LDS copy: the element type itself (u32 keys: 32-bit slots -- a 64-bit LDS read of ONE address by all
 // 64 lanes is not broadcast but served lane after lane); free slots hold K(~0), which for u32 keys cannot be told from the key
-// 0xffffffff, so `has_max` says whether that key is a value (it is then the last one: values are ascending).
+// 0xffffffff, so that key never enters the table (dict_sample_build) and `has_max` says whether it is a value (it is then the
+// last one: values are ascending).
 template <typename K>
 __device__ __forceinline__ uint32_t dict_lookup(K v, const K* __restrict__ s_key, const uint16_t* __restrict__ s_idx, uint32_t n_values,
                                                 bool has_max)
@@ -42,37 +47,47 @@ __device__ __forceinline__ uint32_t dict_lookup(K v, const K* __restrict__ s_key
     return 0xffffffffu;
 }
 
-constexpr int kDictNT = 256;
-constexpr int kDictWGs = 2048;
-
-template <typename E>
-__global__ __launch_bounds__(kDictNT) void dict_count_kernel(const E* __restrict__ src, uint32_t n, DictBlock* __restrict__ blk)
+// ONE workgroup (NT = 512 threads): 16 Ki sampled keys (n >= 16384) -> the dictionary, or n_values = 0.  The all-ones key of E's
+// width is handed to dict_build as kDictEmpty, the one value its tables treat apart (zero-extended, a u32 key 0xffffffff used to
+// enter the hash table and, narrowed to 32 bits in the count phase's LDS copy, read as a FREE slot there: every probe chain
+// through it broke, a spurious miss).
+template <typename E, int NT>
+__device__ __forceinline__ void dict_sample_build(const E* __restrict__ src, uint32_t n, DictBlock* __restrict__ blk, unsigned char* smem)
 {
-    __shared__ E s_key[kDictSlots];
-    __shared__ uint16_t s_idx[kDictSlots];
-    __shared__ uint32_t s_cnt[kDictNT / 64][kDictMax];
-    __shared__ uint32_t s_misc[2];
-    const int tid = (int)threadIdx.x;
-    const uint32_t nv = blk->n_values;
-    if (nv == 0u) {   // no dictionary (the keys changed since the host chose this path): the fill kernel's safety net sorts
-        if (blockIdx.x == 0 && tid == 0) blk->miss = 1u;
-        return;
+    constexpr int PER = 16384 / NT;
+    unsigned long long v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const E x = src[probe_sample_index((uint32_t)((int)threadIdx.x * PER + i), n)];
+        v[i] = x == (E)~(E)0 ? kDictEmpty : (unsigned long long)x;
     }
-    for (int i = tid; i < kDictSlots; i += kDictNT) {
+    dict_build<PER, NT>(v, blk, smem);
+}
+
+// Every workgroup of the grid: look up and count src[0, n).  smem: 14 KiB + NT / 64 KiB of the caller's dynamic LDS.
+template <typename E, int NT>
+__device__ __forceinline__ void dict_count_range(const E* __restrict__ src, uint32_t n, DictBlock* __restrict__ blk, uint32_t nv,
+                                                 unsigned char* smem)
+{
+    E* s_key = reinterpret_cast<E*>(smem);                                                  // [kDictSlots]
+    uint16_t* s_idx = reinterpret_cast<uint16_t*>(smem + sizeof(E) * kDictSlots);           // [kDictSlots]
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem + (sizeof(E) + 2) * kDictSlots);     // [NT / 64][kDictMax]
+    const int tid = (int)threadIdx.x;
+    for (int i = tid; i < kDictSlots; i += NT) {
         s_key[i] = (E)blk->slot_key[i];   // (free slots: all ones in either width)
         s_idx[i] = (uint16_t)blk->slot_idx[i];
     }
-    for (int i = tid; i < (kDictNT / 64) * kDictMax; i += kDictNT) (&s_cnt[0][0])[i] = 0u;
-    const bool has_max = blk->value[nv - 1u] == (unsigned long long)(E)~(E)0;   // the all-ones key is a value
+    for (int i = tid; i < (NT / 64) * kDictMax; i += NT) s_cnt[i] = 0u;
+    const bool has_max = blk->value[nv - 1u] == kDictEmpty;   // the all-ones key is a value
     __syncthreads();
-    uint32_t* my = s_cnt[tid >> 6];
+    uint32_t* my = s_cnt + (tid >> 6) * kDictMax;
     bool miss = false;
     constexpr int VEC = 16 / (int)sizeof(E);
     struct alignas(16) Vec { E v[VEC]; };
     const uint32_t nvec = n / VEC;
     const Vec* vsrc = reinterpret_cast<const Vec*>(src);   // sort buffers are 16-byte aligned
     // A wave whose 64 keys are the same value (constant stretches, one dominant value) looks it up and counts it ONCE, in one lane:
-    // 64 lanes on one LDS address are served one after the other (all-equal keys: 0.24 ms in this kernel instead of 0.07).
+    // 64 lanes on one LDS address are served one after the other (all-equal keys: 0.24 ms in this phase instead of 0.07).
     const int lane = tid & 63;
     auto one = [&](E x, bool active) {
         const E x0 = (E)__builtin_amdgcn_readfirstlane((int)(uint32_t)x) |
@@ -91,15 +106,26 @@ __global__ __launch_bounds__(kDictNT) void dict_count_kernel(const E* __restrict
             else atomicAdd(&my[ix], 1u);
         }
     };
-    for (uint32_t i0 = blockIdx.x * kDictNT; i0 < nvec; i0 += gridDim.x * kDictNT) {   // whole waves stay together (the vote above)
-        const uint32_t i = i0 + (uint32_t)tid;
-        const bool active = i < nvec;
-        Vec v;
-        if (active) v = vsrc[i];
+    // whole waves stay together (the vote above); four 16-byte loads in flight per lane
+    const uint32_t step = gridDim.x * (uint32_t)NT;
+    for (uint32_t i0 = blockIdx.x * (uint32_t)NT; i0 < nvec; i0 += 4u * step) {
+        Vec v[4];
+        bool act[4];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) one(active ? v.v[k] : E(0), active);
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * step + (uint32_t)tid;
+            act[u] = i0 + (uint32_t)u * step < nvec && i < nvec;
+            if (act[u]) v[u] = vsrc[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + (uint32_t)u * step < nvec) {   // (uniform over the workgroup)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) one(act[u] ? v[u].v[k] : E(0), act[u]);
+            }
+        }
     }
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && tid < 64) {   // the last n % VEC keys
         const bool active = (uint32_t)tid < n - nvec * VEC;
         one(active ? src[nvec * VEC + (uint32_t)tid] : E(0), active);
     }
@@ -109,93 +135,67 @@ __global__ __launch_bounds__(kDictNT) void dict_count_kernel(const E* __restrict
     } else if ((uint32_t)tid < nv) {
         uint32_t c = 0u;
 #pragma unroll
-        for (int w = 0; w < kDictNT / 64; ++w) c += s_cnt[w][tid];
+        for (int w = 0; w < NT / 64; ++w) c += s_cnt[w * kDictMax + tid];
         if (c) __hip_atomic_fetch_add(&blk->count[tid], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // the last workgroup to finish scans the counts (they are only ever touched by agent-scope atomics: no cache to flush)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) s_misc[0] = __hip_atomic_fetch_add(&blk->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_misc[0] != gridDim.x - 1u) return;
-    uint32_t* s_wsum = &s_cnt[0][0];
-    const uint32_t c = (uint32_t)tid < nv ? __hip_atomic_load(&blk->count[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    uint32_t total;
-    const uint32_t ex = block_excl_scan_u32<kDictNT>(c, s_wsum, &total);
-    if ((uint32_t)tid < nv) blk->offset[tid] = ex;
-    if (tid == 0) {
-        blk->offset[nv] = total;
-        if (total != n) __hip_atomic_store(&blk->miss, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a miss elsewhere: counts incomplete)
     }
 }
 
-// Writes the runs -- or, when a key missed the dictionary, sorts the untouched input with the cooperative LSD sort (its first 256
-// workgroups; all resident: the grid is launched with at least that many and they are dispatched first).
-template <typename E>
-__global__ __launch_bounds__(kDictNT) void dict_fill_kernel(E* __restrict__ data, E* __restrict__ tmp, uint32_t n, DictBlock* __restrict__ blk,
-                                                            uint32_t* __restrict__ ctable, uint32_t* fault, uint32_t* host_report,
-                                                            int key_bits, uint32_t chunk)
+// Every workgroup of the grid writes its share [p0, p1) of the runs.  The counts are final (a grid barrier lies between the count
+// phase and this) and only ever touched by agent-scope atomics; every workgroup scans them itself.  Returns false (nothing written)
+// when they do not add up to n (cannot happen without a miss).
+template <typename E, int NT>
+__device__ __forceinline__ bool dict_fill_range(E* __restrict__ data, uint32_t n, DictBlock* __restrict__ blk, uint32_t nv, unsigned char* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the safety net's tile (TileCfg<E, 8, 256, 16>)
-    __shared__ uint32_t s_off[kDictMax + 1];
-    __shared__ unsigned long long s_val[kDictMax];
+    uint32_t* s_off = reinterpret_cast<uint32_t*>(smem);                                    // [kDictMax + 1]
+    unsigned long long* s_val = reinterpret_cast<unsigned long long*>(smem + 2048);          // [kDictMax]
+    uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + 2048 + 8 * kDictMax);
     const int tid = (int)threadIdx.x;
-    const uint32_t miss = __hip_atomic_load(&blk->miss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x == 0 && tid == 0)   // 4 = sorted by counting, 2 = the keys did not fit (as the large sort reports it)
-        __hip_atomic_store(host_report, miss ? 2u : 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (miss) {
-        if (blockIdx.x < 256u) {
-            // (the counters of this sort are void; the next sort's probe starts from its own zeroes)
-            if (blockIdx.x == 0)
-                for (int i = tid; i < kDictMax; i += kDictNT) blk->count[i] = 0u;
-            coop_lsd_sort<E, kDictNT, 16>(data, tmp, n, ctable, ctable + 256 * 256, &blk->bar, fault, smem, key_bits, 0u, 256u);
-        }
-        return;
+    const uint32_t c = (uint32_t)tid < nv ? __hip_atomic_load(&blk->count[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    uint32_t total;
+    const uint32_t ex = block_excl_scan_u32<NT>(c, s_wsum, &total);
+    if ((uint32_t)tid < nv) {
+        s_off[tid] = ex;
+        s_val[tid] = blk->value[tid];
     }
-    const uint32_t nv = blk->n_values;
-    for (int i = tid; i <= (int)nv; i += kDictNT) s_off[i] = blk->offset[i];
-    for (int i = tid; i < (int)nv; i += kDictNT) s_val[i] = blk->value[i];
+    if (tid == 0) s_off[nv] = total;
     __syncthreads();
-    const uint32_t p0 = blockIdx.x * chunk;
-    if (p0 >= n) {
-        // (nothing to write; the first idle workgroup -- there is one unless the grid is exact -- would be a place for chores)
-    } else {
-        const uint32_t p1 = p0 + chunk < n ? p0 + chunk : n;
-        // value of position p0: the last index whose offset is <= p0
-        uint32_t lo = 0u, hi = nv;
-        while (hi - lo > 1u) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_off[mid] <= p0) lo = mid; else hi = mid;
-        }
-        uint32_t ix = lo;
-        while (ix + 1u < nv && s_off[ix + 1u] <= p0) ++ix;   // (empty runs)
-        // the chunk in stretches of one value each (nearly always one stretch: a run is n / 256 keys and more)
-        uint32_t p = p0;
-        while (p < p1) {
-            while (ix + 1u < nv && s_off[ix + 1u] <= p) ++ix;
-            const uint32_t end = s_off[ix + 1u] < p1 ? s_off[ix + 1u] : p1;
-            const E v = (E)s_val[ix];
-            constexpr uint32_t VEC = 16u / (uint32_t)sizeof(E);
-            struct alignas(16) Vec { E v[VEC]; };
-            const uint32_t a0 = (p + VEC - 1u) / VEC * VEC;             // first 16-byte boundary inside
-            const uint32_t a1 = end / VEC * VEC;
-            if (a0 < a1) {
-                Vec vv;
-#pragma unroll
-                for (uint32_t k = 0; k < VEC; ++k) vv.v[k] = v;
-                Vec* out = reinterpret_cast<Vec*>(data);
-                for (uint32_t i = a0 / VEC + (uint32_t)tid; i < a1 / VEC; i += kDictNT) out[i] = vv;
-                for (uint32_t i = p + (uint32_t)tid; i < a0; i += kDictNT) data[i] = v;
-                for (uint32_t i = a1 + (uint32_t)tid; i < end; i += kDictNT) data[i] = v;
-            } else {
-                for (uint32_t i = p + (uint32_t)tid; i < end; i += kDictNT) data[i] = v;
-            }
-            p = end;
-        }
+    if (total != n) return false;
+    constexpr uint32_t VEC = 16u / (uint32_t)sizeof(E);
+    const uint32_t chunk = ((n + gridDim.x - 1u) / gridDim.x + VEC - 1u) / VEC * VEC;
+    const uint64_t p064 = (uint64_t)blockIdx.x * chunk;
+    if (p064 >= n) return true;
+    const uint32_t p0 = (uint32_t)p064;
+    const uint32_t p1 = p064 + chunk < n ? p0 + chunk : n;
+    // value of position p0: the last index whose offset is <= p0
+    uint32_t lo = 0u, hi = nv;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_off[mid] <= p0) lo = mid; else hi = mid;
     }
-    // the counters go back to zero for the next sort (every workgroup has read the offsets it needs; counts are not read here)
-    if (blockIdx.x == gridDim.x - 1u)
-        for (int i = tid; i < kDictMax; i += kDictNT) blk->count[i] = 0u;
+    uint32_t ix = lo;
+    // the chunk in stretches of one value each (nearly always one stretch: a run is n / 256 keys and more)
+    uint32_t p = p0;
+    while (p < p1) {
+        while (ix + 1u < nv && s_off[ix + 1u] <= p) ++ix;   // (empty runs)
+        const uint32_t end = s_off[ix + 1u] < p1 ? s_off[ix + 1u] : p1;
+        const E v = (E)s_val[ix];   // (kDictEmpty narrows to the all-ones key of E's width)
+        struct alignas(16) Vec { E v[VEC]; };
+        const uint32_t a0 = (p + VEC - 1u) / VEC * VEC;             // first 16-byte boundary inside
+        const uint32_t a1 = end / VEC * VEC;
+        if (a0 < a1) {
+            Vec vv;
+#pragma unroll
+            for (uint32_t k = 0; k < VEC; ++k) vv.v[k] = v;
+            Vec* out = reinterpret_cast<Vec*>(data);
+            for (uint32_t i = a0 / VEC + (uint32_t)tid; i < a1 / VEC; i += NT) out[i] = vv;
+            for (uint32_t i = p + (uint32_t)tid; i < a0; i += NT) data[i] = v;
+            for (uint32_t i = a1 + (uint32_t)tid; i < end; i += NT) data[i] = v;
+        } else {
+            for (uint32_t i = p + (uint32_t)tid; i < end; i += NT) data[i] = v;
+        }
+        p = end;
+    }
+    return true;
 }
 
 }  // namespace adlhip

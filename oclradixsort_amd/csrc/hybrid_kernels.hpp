@@ -18,7 +18,7 @@
 
 #include "radix_kernels.hpp"
 #include "onesweep_kernels.hpp"
-#include "dict_build.hpp"
+#include "dict_kernels.hpp"
 
 namespace adlhip {
 
@@ -65,6 +65,68 @@ struct MidCoop {          // what the safety net needs beside the two arrays (ta
     uint32_t n;
 };
 
+// The net's count phase: the digits (key >> sb) & dm of src[e0, e1) into the calling wave's 256 LDS counters.  e0 is a multiple
+// of a tile, so the run starts on a 16-byte boundary: 16-byte loads, four in flight per lane while the four before them are
+// counted (round 3's loop read one key per lane and iteration and waited for it: 0.4-0.5 ms of a 0.7-ms pass at 64 Mi keys).
+// A round whose keys all share one digit -- constant, sorted, few-valued input -- is added by one lane (64 lanes on ONE LDS
+// counter are served one after the other).
+template <typename E, int NT>
+__device__ __forceinline__ void coop_count_range(const E* __restrict__ src, uint32_t e0, uint32_t e1, uint32_t* my_hist, int sb, uint32_t dm)
+{
+    constexpr int VEC = 16 / (int)sizeof(E);
+    struct alignas(16) Vec { E v[VEC]; };
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const int tid = (int)threadIdx.x;
+    if (e1 <= e0) return;
+    const v4u* vraw = reinterpret_cast<const v4u*>(src + e0);
+    auto vld = [&](uint32_t at) -> Vec {
+        const v4u r = vraw[at];
+        Vec o;
+        __builtin_memcpy(&o, &r, 16);
+        return o;
+    };
+    auto dig = [&](E x) -> uint32_t { return (uint32_t)(x >> sb) & dm; };
+    auto bump4 = [&](const Vec& a, const Vec& b, const Vec& c, const Vec& d4) {
+        const uint32_t da = dig(a.v[0]);
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)da);
+        if (__all(da == d0)) {
+            bool same = true;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) same = same && dig(a.v[k]) == d0 && dig(b.v[k]) == d0 && dig(c.v[k]) == d0 && dig(d4.v[k]) == d0;
+            if (__all(same)) {
+                const uint64_t act = __ballot(true);
+                if (mbcnt64(act) == 0u) atomicAdd(&my_hist[d0], (uint32_t)(4 * VEC * __popcll(act)));
+                return;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            atomicAdd(&my_hist[dig(a.v[k])], 1u);
+            atomicAdd(&my_hist[dig(b.v[k])], 1u);
+            atomicAdd(&my_hist[dig(c.v[k])], 1u);
+            atomicAdd(&my_hist[dig(d4.v[k])], 1u);
+        }
+    };
+    const uint32_t nvec = (e1 - e0) / VEC;
+    uint32_t i = (uint32_t)tid;
+    if (i + 3u * NT < nvec) {
+        Vec a = vld(i), b = vld(i + NT), c = vld(i + 2 * NT), d4 = vld(i + 3 * NT);
+        i += 4u * NT;
+        for (; i + 3u * NT < nvec; i += 4u * NT) {
+            const Vec na = vld(i), nb = vld(i + NT), nc = vld(i + 2 * NT), nd = vld(i + 3 * NT);
+            bump4(a, b, c, d4);
+            a = na; b = nb; c = nc; d4 = nd;
+        }
+        bump4(a, b, c, d4);
+    }
+    for (; i < nvec; i += NT) {
+        const Vec a = vld(i);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) atomicAdd(&my_hist[dig(a.v[k])], 1u);
+    }
+    for (uint32_t s = e0 + nvec * VEC + (uint32_t)tid; s < e1; s += NT) atomicAdd(&my_hist[dig(src[s])], 1u);
+}
+
 template <typename E, int NT, int K>
 __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table, uint32_t* __restrict__ totals,
                                               uint32_t* bar, uint32_t* fault, unsigned char* smem, int key_bits = 32,
@@ -96,8 +158,7 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
         // ---- count the digits of this workgroup's run of tiles --------------------------------------------------------
         for (int i = tid; i < NW * 256; i += NT) hist[i] = 0u;
         __syncthreads();
-        for (uint32_t i = e0 + (uint32_t)tid; i < e1; i += (uint32_t)NT)
-            atomicAdd(&hist[w * 256 + ((uint32_t)(src[i] >> sb) & dm)], 1u);
+        coop_count_range<E, NT>(src, e0, e1, hist + w * 256, sb, dm);
         __syncthreads();
         if (tid < 256) {
             uint32_t c = 0u;
@@ -143,6 +204,36 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
     if (src != data) {   // odd number of passes: the result sits in tmp (the barrier above made it visible)
         for (size_t i = (size_t)wg * NT + (size_t)tid; i < n; i += (size_t)wgs * NT) data[i] = src[i];
     }
+}
+
+// The large sort's safety net, run by the workgroups of its offsets kernel when a run did not fit its slab (the input is then
+// untouched: the passes write only slabs).  dict != nullptr (whole-key sorts of keys): first the counting sort of
+// dict_kernels.hpp -- sample, look up and count, fill -- and only if the keys take more than 256 values, or one of them missed the
+// dictionary, the LSD passes.  `bar` is zero on entry.  No launch of its own, no word for the host to read: the same input takes the
+// same time whether it is the handle's first sort or its hundredth.
+template <typename E, int NT, int K>
+__device__ __forceinline__ void net_sort(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table, uint32_t* bar, uint32_t* fault,
+                                         unsigned char* smem, int key_bits, DictBlock* dict, uint32_t* stats, uint32_t target0 = 0u)
+{
+    uint32_t target = target0;
+    const uint32_t wgs = gridDim.x;
+    // stats[0] = nets run, stats[1] = of those, sorted by counting ("stat.net_runs" / "stat.net_counting": tests, bench)
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(stats + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (dict && n >= 16384u) {
+        if (blockIdx.x == 0) dict_sample_build<E, NT>(data, n, dict, smem);
+        if (!grid_barrier(bar, target, wgs, fault)) return;
+        const uint32_t nv = __hip_atomic_load(&dict->n_values, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nv) {
+            dict_count_range<E, NT>(data, n, dict, nv, smem);
+            if (!grid_barrier(bar, target, wgs, fault)) return;
+            if (!__hip_atomic_load(&dict->miss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && dict_fill_range<E, NT>(data, n, dict, nv, smem)) {
+                if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(stats + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            __syncthreads();   // (the fill's LDS is the LSD sort's)
+        }
+    }
+    coop_lsd_sort<E, NT, K>(data, tmp, n, table, table + 256 * wgs, bar, fault, smem, key_bits, target);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -988,85 +1079,6 @@ __global__ __launch_bounds__(1024) void probe_positions_selftest_kernel(uint32_t
     if (bad) atomicAdd(out + 1, bad);
 }
 
-// Before a device handle trusts the large sort with its keys it looks at them once: ONE workgroup samples 16 Ki keys, places
-// the first digit exactly as the sort would (msd2_placement's rule on the sample's OR / AND) and counts the samples per bucket;
-// a bucket with 1.75 x the mean (64 samples, + 6 sd) would not fit its slab.  The verdict goes into the same pinned
-// word the sort's own report uses (1 = fits, 2 = does not), to be read -- without synchronising -- by a later call; the sort
-// it rides along with takes the per-digit passes.  Costs ~20 us, once per handle (and once after every back-off); what it
-// saves is the safety net's 2.8 ms on the first sort of clustered / constant / low-entropy keys.  (Skew that only shows at
-// the scale of single segments is not seen here; the sort's own check remains.)
-template <typename E>
-__global__ __launch_bounds__(1024) void msd2_probe_kernel(const E* __restrict__ src, uint32_t n, int key_bits, uint32_t* host_report,
-                                                          DictBlock* __restrict__ dict /* or nullptr: no counting sort for this sort */,
-                                                          uint32_t dup_limit /* samples that may repeat an earlier one */)
-{
-    __shared__ uint32_t s_seen[8192];   // 256 Ki bits, one per hashed sample value
-    __shared__ uint32_t s_dups;
-    __shared__ unsigned long long s_or[16], s_and[16];
-    __shared__ uint32_t s_hist[256];
-    __shared__ uint32_t s_top;
-    const int tid = (int)threadIdx.x;
-    const unsigned long long kmask = key_bits >= 64 ? ~0ull : ((1ull << key_bits) - 1ull);
-    unsigned long long v[16];
-    unsigned long long o = 0ull, a = ~0ull;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        // sample k of 16384: somewhere inside the k-th 16384th of the array (a fixed stride would see one phase of periodic keys only)
-        v[i] = (unsigned long long)src[probe_sample_index((uint32_t)(tid * 16 + i), n)] & kmask;
-        o |= v[i];
-        a &= v[i];
-    }
-#pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) {
-        o |= __shfl_xor(o, sh);
-        a &= __shfl_xor(a, sh);
-    }
-    if ((tid & 63) == 0) {
-        s_or[tid >> 6] = o;
-        s_and[tid >> 6] = a;
-    }
-    if (tid < 256) s_hist[tid] = 0u;
-    for (int i = tid; i < 8192; i += 1024) s_seen[i] = 0u;
-    if (tid == 0) s_dups = 0u;
-    __syncthreads();
-    if (tid == 0) {
-        for (int i = 1; i < 16; ++i) {
-            o |= s_or[i];
-            a &= s_and[i];
-        }
-        const unsigned long long diff = o ^ a;
-        int top = diff ? 64 - __builtin_clzll(diff) : 0;
-        if (top < 16) top = 16;
-        s_top = (uint32_t)top;
-    }
-    {   // Heavy duplication -- a few thousand distinct values, each with tens of thousands of copies -- overflows the SEGMENT slabs,
-        // which no first-digit histogram shows (4096 values: every bucket is fine, the first sort went through the 2.8-ms safety
-        // net).  Samples that repeat an earlier one give it away: 16 Ki samples of keys without repeats collide ~500 times in a
-        // 256 Ki-bit table, of D distinct values S - D (1 - e^(-S/D)) times; the host passes the count at which a value outgrows a slab.
-        uint32_t mine = 0u;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t h = (uint32_t)((v[i] * 0x9E3779B97F4A7C15ull) >> 46);   // 18 bits
-            const uint32_t bit = 1u << (h & 31u);
-            mine += (atomicOr(&s_seen[h >> 5], bit) & bit) ? 1u : 0u;
-        }
-        if (mine) atomicAdd(&s_dups, mine);
-    }
-    __syncthreads();
-    const int sb = (int)s_top - 8;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) atomicAdd(&s_hist[(uint32_t)(v[i] >> sb) & 255u], 1u);
-    __syncthreads();
-    // mean 64 samples per bucket, sd 8; the slabs take 1.5 x the mean.  112 = + 6 sd: uniform keys are never turned away, and
-    // what is turned away (1.75 x and more in some bucket) would certainly not have fitted
-    const int over = __syncthreads_or((tid < 256 && s_hist[tid & 255] > 112u) || s_dups > dup_limit);
-    // few distinct values among the samples: the dictionary for the counting sort (dict_kernels.hpp), and the host is told (4)
-    uint32_t few = 0u;
-    if (dict) few = dict_build<16>(v, dict);
-    // 3 = "the probe sees no obstacle" -- not the same as a sort that went through (1): only that resets the host's back-off
-    if (tid == 0) __hip_atomic_store(host_report, few ? 4u : (over ? 2u : 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 constexpr int kSampleWGs = 16;
 
 template <typename E>
@@ -1112,6 +1124,9 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
     uint32_t* __restrict__ s_wcnt = reinterpret_cast<uint32_t*>(smem + C::OFF_WCNT);   // [NW][BINS]
     uint32_t* __restrict__ s_goff = reinterpret_cast<uint32_t*>(smem + C::OFF_GOFF);   // [BINS]
     if (a.zero_me && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.zero_me, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (PASS >= 1) {   // a run has outgrown its slab: the net will sort (net_sort), nothing written from here on is read
+        if (__hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    }
     uint32_t base, valid, cursor_base = 0u;
     uint32_t lin = 0u;   // PASS == 3: index of the tile's first element if the tile lies inside one sub-slab, else ~0
     if constexpr (PASS == 3) {
@@ -1367,34 +1382,40 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
 // ------------------------------------------------------------------------------------------
 // The safety net lives in this kernel too: its 256 workgroups are all resident, so when the overflow flag is set they go on to
 // sort the untouched input with the cooperative LSD sort (a launch of its own that returns at once cost 5-6 us per sort).
-template <typename E>
-__global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, uint32_t* cursors_b, uint32_t* flag, uint32_t* done,
-                                                           uint32_t* bar, uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_off,
-                                                           uint32_t* __restrict__ mode, uint32_t* host_mode, uint32_t n,
-                                                           uint32_t* sample, E* data, E* tmp, uint32_t* __restrict__ ctable,
-                                                           uint32_t* fault, int key_bits, uint32_t d2_shift /* 8 - w, slot_to_segment */)
+template <typename E, int NT, int K>
+__global__ __launch_bounds__(NT) void msd2_offsets_kernel(uint32_t* cursors_a, uint32_t* cursors_b, uint32_t* flag, uint32_t* done,
+                                                          uint32_t* bar, uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_off,
+                                                          uint32_t* __restrict__ mode, uint32_t n,
+                                                          uint32_t* sample, E* data, E* tmp, uint32_t* __restrict__ ctable,
+                                                          uint32_t* fault, int key_bits, uint32_t d2_shift /* 8 - w, slot_to_segment */,
+                                                          DictBlock* dict /* the net's counting sort, or nullptr */, uint32_t* stats)
 {
-    __shared__ uint32_t s_wsum[256 / 64 + 1];
+    static_assert(NT >= 256, "one thread per digit");
+    __shared__ uint32_t s_wsum[NT / 64 + 1];
     __shared__ uint32_t s_misc[4];
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the safety net's tile (TileCfg<E, 8, 256, 16>)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the safety net's tile (TileCfg<E, 8, NT, K>)
     const int t = (int)threadIdx.x;
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = blockIdx.x;   // the grid has at least 256 workgroups: workgroup b < 256 serves bucket b
     // final since pass 2 has completed; every workgroup reads it BEFORE it counts itself done, the last one done clears it
     const uint32_t overflow = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t ca = __hip_atomic_load(cursors_a + 32 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one line per cursor
-    const uint32_t exa = block_excl_scan_u32<256>(ca, s_wsum, nullptr);
-    if (t == (int)b) s_misc[0] = exa;
-    const uint32_t cb = __hip_atomic_load(cursors_b + b * 256u + (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t exb = block_excl_scan_u32<256>(cb, s_wsum, nullptr);
-    __syncthreads();
-    seg_cnt[b * 256u + (uint32_t)t] = cb;
-    seg_off[b * 256u + (uint32_t)t] = s_misc[0] + exb;
-    __hip_atomic_store(cursors_b + b * 256u + (uint32_t)t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // the first pass's cursors are read by every workgroup: the last one to have read them clears them and publishes the mode
+    if (b < 256u) {
+        const uint32_t ca = t < 256 ? __hip_atomic_load(cursors_a + 32 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;   // one line per cursor
+        const uint32_t exa = block_excl_scan_u32<NT>(ca, s_wsum, nullptr);
+        if (t == (int)b) s_misc[0] = exa;
+        const uint32_t cb = t < 256 ? __hip_atomic_load(cursors_b + b * 256u + (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t exb = block_excl_scan_u32<NT>(cb, s_wsum, nullptr);
+        __syncthreads();
+        if (t < 256) {
+            seg_cnt[b * 256u + (uint32_t)t] = cb;
+            seg_off[b * 256u + (uint32_t)t] = s_misc[0] + exb;
+            __hip_atomic_store(cursors_b + b * 256u + (uint32_t)t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // the first pass's cursors are read by the first 256 workgroups: the last workgroup to be done clears them and publishes the mode
     if (t == 0) s_misc[1] = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_misc[1] == gridDim.x - 1u) {
-        __hip_atomic_store(cursors_a + 32 * t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < 256) __hip_atomic_store(cursors_a + 32 * t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == 0) {
             *mode = overflow ? 1u : 0u;   // the finish returns at once when it is set
             mode[kDynHardCnt] = 0u;
@@ -1409,12 +1430,11 @@ __global__ __launch_bounds__(256) void msd2_offsets_kernel(uint32_t* cursors_a, 
             }
             __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(host_mode, 1u + (overflow ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     if (overflow) {   // `bar` is zero here: msd2_sample_kernel, the first launch of every sort, clears it
         __syncthreads();
-        coop_lsd_sort<E, 256, 16>(data, tmp, n, ctable, ctable + 256 * 256, bar, fault, smem, key_bits);
+        net_sort<E, NT, K>(data, tmp, n, ctable, bar, fault, smem, key_bits, dict, stats);
     }
 }
 
@@ -1525,6 +1545,8 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
     // workgroups that run at the same time work on the same few buckets and write into the same few hundred segment slabs
     // (chain = i % 256, which spreads every moment's writes over all 65536 slabs, measured 0.299 vs 0.272 ms at 64 Mi pairs and
     // 0.637 vs 0.527 ms at 128 Mi)
+    // pass B when pass A has raised the overflow flag (final by now): every workgroup leaves, the net sorts (net_sort)
+    if (a.which_digit == 2 && __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const uint32_t chain = a.which_digit == 2 ? blockIdx.x / a.rows_per_chain : blockIdx.x % a.chains;
     // (pass B with a narrow second digit: the field sits 8 - w bits higher, see slot_to_segment)
     const int start_bit = (int)a.place->top - 8 * a.which_digit + (a.which_digit == 2 ? 8 - (int)a.seg_shift : 0);
@@ -1769,28 +1791,32 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
 // Between pass B and the finish: workgroup b turns bucket b's final counts (the last status row of chain b) into the
 // segments' sizes and output offsets; the last workgroup publishes the mode word and the host's hint.
 // As in the keys-only form, the safety net runs in this kernel when the overflow flag is set.
-template <typename E, int TILE>
-__global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __restrict__ status_a, uint32_t rows_per_chain_a, uint32_t slice,
+template <typename E, int TILE, int NT, int K>
+__global__ __launch_bounds__(NT) void msd2s_offsets_kernel(const uint32_t* __restrict__ status_a, uint32_t rows_per_chain_a, uint32_t slice,
                                                             uint32_t pieces,
                                                             const uint32_t* __restrict__ status_b, uint32_t rows_per_chain_b,
                                                             uint32_t src_stride, uint32_t* flag, uint32_t* done, uint32_t* bar,
                                                             uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_off,
-                                                            uint32_t* __restrict__ mode, uint32_t* host_mode, uint32_t n,
+                                                            uint32_t* __restrict__ mode, uint32_t n,
                                                             const StablePlace* __restrict__ place, E* data, E* tmp,
                                                             uint32_t* __restrict__ ctable, uint32_t* fault, uint32_t* soa_keys,
                                                             uint32_t* soa_vals, uint32_t* cursors_b /* hybrid form, else nullptr */,
-                                                            uint32_t d2_shift /* 8 - w (slot_to_segment); stable second pass: 0 */)
+                                                            uint32_t d2_shift /* 8 - w (slot_to_segment); stable second pass: 0 */,
+                                                            DictBlock* dict /* whole-key sorts of keys: the net's counting sort, else nullptr */,
+                                                            uint32_t* stats)
 {
-    __shared__ uint32_t s_wsum[256 / 64 + 1];
+    static_assert(NT >= 256, "one thread per digit");
+    __shared__ uint32_t s_wsum[NT / 64 + 1];
     __shared__ uint32_t s_misc[4];
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the safety net's tile (TileCfg<E, 8, 256, 16>)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the safety net's tile (TileCfg<E, 8, NT, K>)
     const int t = (int)threadIdx.x;
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = blockIdx.x;   // at least 256 workgroups: workgroup b < 256 serves bucket b
     // final since pass B has completed; read by every workgroup BEFORE it counts itself done, cleared by the last one done
     const uint32_t overflow = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b < 256u) {
     // thread t: size of bucket t = sum of its 16 sub-slabs; and the tiles pass B made of it
     uint32_t size_t_ = 0u, tiles_t = 0u;
-    for (uint32_t c = 0; c < pieces; ++c) {
+    for (uint32_t c = 0; c < pieces && t < 256; ++c) {
         const uint32_t c0 = c * slice;
         if (c0 >= n) break;
         const uint32_t len = (c0 + slice < n ? c0 + slice : n) - c0;
@@ -1800,23 +1826,28 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
         size_t_ += cnt;
     }
     tiles_t = (size_t_ + (uint32_t)TILE - 1u) / (uint32_t)TILE;   // pass B's tiles run across the sub-slabs
-    const uint32_t exa = block_excl_scan_u32<256>(size_t_, s_wsum, nullptr);
+    const uint32_t exa = block_excl_scan_u32<NT>(size_t_, s_wsum, nullptr);
     if (t == (int)b) {
         s_misc[0] = exa;
         s_misc[1] = tiles_t;
     }
     __syncthreads();
     const uint32_t tiles_b = s_misc[1];
-    uint32_t cb;
-    if (cursors_b) {   // hybrid form: the second pass placed its runs with cursors [bucket][digit]; they go back to zero here
-        cb = __hip_atomic_load(cursors_b + b * 256u + (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(cursors_b + b * 256u + (uint32_t)t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        cb = tiles_b ? (status_b[((size_t)b * rows_per_chain_b + tiles_b - 1u) * 256u + (uint32_t)t] & kValMask) : 0u;
+    uint32_t cb = 0u;
+    if (t < 256) {
+        if (cursors_b) {   // hybrid form: the second pass placed its runs with cursors [bucket][digit]; they go back to zero here
+            cb = __hip_atomic_load(cursors_b + b * 256u + (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(cursors_b + b * 256u + (uint32_t)t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            cb = tiles_b ? (status_b[((size_t)b * rows_per_chain_b + tiles_b - 1u) * 256u + (uint32_t)t] & kValMask) : 0u;
+        }
     }
-    const uint32_t exb = block_excl_scan_u32<256>(cb, s_wsum, nullptr);
-    seg_cnt[b * 256u + (uint32_t)t] = cb;
-    seg_off[b * 256u + (uint32_t)t] = s_misc[0] + exb;
+    const uint32_t exb = block_excl_scan_u32<NT>(cb, s_wsum, nullptr);
+    if (t < 256) {
+        seg_cnt[b * 256u + (uint32_t)t] = cb;
+        seg_off[b * 256u + (uint32_t)t] = s_misc[0] + exb;
+    }
+    }
     if (t == 0) s_misc[2] = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_misc[2] == gridDim.x - 1u && t == 0) {
@@ -1827,22 +1858,21 @@ __global__ __launch_bounds__(256) void msd2s_offsets_kernel(const uint32_t* __re
         seg_off[65536] = n;
         __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(host_mode, 1u + (overflow ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (overflow) {   // `bar` is zero here: msd2s_prep_kernel, the first launch of every sort, clears it
         __syncthreads();
         uint32_t target = 0u;
         if constexpr (sizeof(E) == 8) {
             if (soa_keys) {   // SoA input: pack it into `data` (here: the first slab area), sort that, unpack
-                for (size_t i = (size_t)blockIdx.x * 256u + (size_t)t; i < n; i += (size_t)gridDim.x * 256u)
+                for (size_t i = (size_t)blockIdx.x * NT + (size_t)t; i < n; i += (size_t)gridDim.x * NT)
                     data[i] = (E)soa_keys[i] | ((E)soa_vals[i] << 32);
                 if (!grid_barrier(bar, target, gridDim.x, fault)) return;
             }
         }
-        coop_lsd_sort<E, 256, 16>(data, tmp, n, ctable, ctable + 256 * 256, bar, fault, smem, (int)place->sort_bits, target);
+        net_sort<E, NT, K>(data, tmp, n, ctable, bar, fault, smem, (int)place->sort_bits, soa_keys ? nullptr : dict, stats, target);
         if constexpr (sizeof(E) == 8) {
             if (soa_keys) {   // the sort's last phase ends with a grid barrier: `data` is complete
-                for (size_t i = (size_t)blockIdx.x * 256u + (size_t)t; i < n; i += (size_t)gridDim.x * 256u) {
+                for (size_t i = (size_t)blockIdx.x * NT + (size_t)t; i < n; i += (size_t)gridDim.x * NT) {
                     const E x = data[i];
                     soa_keys[i] = (uint32_t)x;
                     soa_vals[i] = (uint32_t)(x >> 32);

@@ -96,23 +96,30 @@ class Pprims:
         else:
             raise AdlHipError("radixSort: unsupported element type %s" % inout.dtype)
 
-    def radixSortSoA(self, device, keys, values, n, sortBits=32):
-        """Key-value sort on separate u32 key and u32 value buffers (structure of arrays): ascending
-        by key, stable, values follow their keys.  Same contract as radixSort on {key, value} pairs."""
-        assert keys.dtype == np.uint32 and values.dtype == np.uint32
+    def radixSortSoA(self, device, keys, values, n, sortBits=None):
+        """Key-value sort on separate key and value buffers (structure of arrays): ascending by key,
+        stable, values follow their keys.  Same contract as radixSort on {key, value} pairs.  Keys: uint32 or
+        uint64; values: any element type of 4, 8 or 16 bytes (u32 + u32 is the reference kernel's own layout,
+        RadixSortKeyValueKernels.cl:354-509)."""
+        kb, vb = keys.dtype.itemsize, values.dtype.itemsize
+        if keys.dtype not in (np.uint32, np.uint64) or vb not in (4, 8, 16):
+            raise AdlHipError("radixSortSoA: keys %s / values %s unsupported" % (keys.dtype, values.dtype))
+        if sortBits is None:
+            sortBits = 8 * kb
         if device is None:
             raise AdlHipError("radixSortSoA needs a device")
         n = int(n)
         lib = _lib.load()
-        tb = ctypes.c_size_t()
+        tk = ctypes.c_size_t()
+        tv = ctypes.c_size_t()
         wb = ctypes.c_size_t()
-        check(lib.adlhip_radix_sort_scratch_bytes_for(device._h, ELEM_SOA32, n, int(sortBits), 1, ctypes.byref(tb), ctypes.byref(wb)),
-              "adlhip_radix_sort_scratch_bytes_for")
-        self._scratch(device, 2 * tb.value, wb.value)          # tmp keys + tmp values, back to back
+        check(lib.adlhip_radix_sort_soa_scratch_bytes(device._h, kb, vb, n, int(sortBits), ctypes.byref(tk), ctypes.byref(tv),
+                                                      ctypes.byref(wb)), "adlhip_radix_sort_soa_scratch_bytes")
+        self._scratch(device, tk.value + tv.value, wb.value)          # tmp keys + tmp values, back to back
         tmp_k = self.m_tmp.ptr()
-        tmp_v = ctypes.c_void_p(self.m_tmp.m_ptr + tb.value) if self.m_tmp.m_ptr else None
-        check(lib.adlhip_radix_sort_soa32(device._h, keys.ptr(), values.ptr(), tmp_k, tmp_v, self.m_work.ptr(),
-                                          self.m_work.getSize(), n, int(sortBits)), "radixSortSoA")
+        tmp_v = ctypes.c_void_p(self.m_tmp.m_ptr + tk.value) if self.m_tmp.m_ptr else None
+        check(lib.adlhip_radix_sort_soa(device._h, keys.ptr(), kb, values.ptr(), vb, tmp_k, tmp_v, self.m_work.ptr(),
+                                        self.m_work.getSize(), n, int(sortBits)), "radixSortSoA")
 
     def radixSort64(self, device, inout, n, sortBits=64):
         assert inout.dtype == np.uint64

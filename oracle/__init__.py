@@ -48,6 +48,8 @@ def _load_oracle():
     lib.oracle_radix_sort_u32_bits.restype = ctypes.c_int
     lib.oracle_radix_sort_e64_bits.argtypes = [_u64p, ctypes.c_size_t, ctypes.c_int]
     lib.oracle_radix_sort_e64_bits.restype = ctypes.c_int
+    lib.oracle_radix_sort_soa.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_int]
+    lib.oracle_radix_sort_soa.restype = ctypes.c_int
     lib.oracle_exclusive_scan_u32.argtypes = [_u32p, _u32p, ctypes.c_size_t]
     lib.oracle_exclusive_scan_u32.restype = ctypes.c_uint32
     lib.oracle_fnv1a64.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
@@ -139,6 +141,19 @@ def sort_e64_bits(elems, sort_bits):
     a = _own(elems, np.uint64)
     assert lib().oracle_radix_sort_e64_bits(_p64(a), a.size, sort_bits) == 0
     return a
+
+
+def sort_soa(keys, values, sort_bits=None):
+    """Stable key-value sort on separate arrays: keys uint32 / uint64, values of any fixed-width dtype.  Returns
+    (sorted keys, values in their keys' order)."""
+    k = np.array(keys, copy=True, order="C")
+    v = np.array(values, copy=True, order="C")
+    assert k.dtype in (np.uint32, np.uint64) and k.ndim == 1 and v.shape[0] == k.shape[0]
+    vb = v.dtype.itemsize * int(np.prod(v.shape[1:], dtype=np.int64))
+    bits = 8 * k.dtype.itemsize if sort_bits is None else int(sort_bits)
+    assert lib().oracle_radix_sort_soa(k.ctypes.data_as(ctypes.c_void_p), k.dtype.itemsize, v.ctypes.data_as(ctypes.c_void_p), vb,
+                                       k.shape[0], bits) == 0
+    return k, v
 
 
 def exclusive_scan_u32(src):

@@ -170,6 +170,43 @@ int oracle_radix_sort_e64_bits(uint64_t *data, size_t n, int sort_bits)
     return 0;
 }
 
+/* Key-value sort on SEPARATE key and value arrays with keys of 4 or 8 bytes and values of any width: the contract of
+ * the reference's SoA kernel (Tahoe/ClKernels/RadixSortKeyValueKernels.cl:354-509: gSrc / gSrcVal -> gDst / gDstVal, one stable
+ * 4-bit pass per call) run for ib = 0,4,..,sortBits-4 as Pprims.cpp:357 does: keys ascending by their low sort_bits bits, equal
+ * ones in input order, every value beside its key.  Restated as the same stable 4-bit LSD passes over an index permutation
+ * (the values' width then does not enter the passes), applied to both arrays at the end.
+ * For 4-byte keys and values this must equal oracle_radix_sort_kv32 on the packed pairs (tests/test_oracle.py pins it there). */
+int oracle_radix_sort_soa(void *keys, int key_bytes, void *vals, int value_bytes, size_t n, int sort_bits)
+{
+    if ((key_bytes != 4 && key_bytes != 8) || value_bytes <= 0 || sort_bits < 0 || sort_bits > 8 * key_bytes) return 2;
+    if (n == 0 || sort_bits == 0) return 0;
+    uint64_t *k = (uint64_t *)malloc(n * sizeof(uint64_t));
+    uint32_t *a = (uint32_t *)malloc(n * sizeof(uint32_t));
+    uint32_t *b = (uint32_t *)malloc(n * sizeof(uint32_t));
+    unsigned char *out = (unsigned char *)malloc(n * (size_t)(key_bytes > value_bytes ? key_bytes : value_bytes));
+    if (!k || !a || !b || !out) { free(k); free(a); free(b); free(out); return 1; }
+    for (size_t i = 0; i < n; i++) {
+        k[i] = key_bytes == 4 ? ((const uint32_t *)keys)[i] : ((const uint64_t *)keys)[i];
+        a[i] = (uint32_t)i;
+    }
+    uint32_t *src = a, *dst = b;
+    for (int start_bit = 0; start_bit < sort_bits; start_bit += 4) {
+        size_t cursor[16];
+        memset(cursor, 0, sizeof(cursor));
+        for (size_t i = 0; i < n; i++) cursor[(k[src[i]] >> start_bit) & 15u]++;
+        size_t sum = 0;
+        for (int d = 0; d < 16; d++) { size_t c = cursor[d]; cursor[d] = sum; sum += c; }
+        for (size_t i = 0; i < n; i++) dst[cursor[(k[src[i]] >> start_bit) & 15u]++] = src[i];
+        uint32_t *t = src; src = dst; dst = t;
+    }
+    for (size_t i = 0; i < n; i++) memcpy(out + i * (size_t)key_bytes, (const unsigned char *)keys + (size_t)src[i] * key_bytes, (size_t)key_bytes);
+    memcpy(keys, out, n * (size_t)key_bytes);
+    for (size_t i = 0; i < n; i++) memcpy(out + i * (size_t)value_bytes, (const unsigned char *)vals + (size_t)src[i] * value_bytes, (size_t)value_bytes);
+    memcpy(vals, out, n * (size_t)value_bytes);
+    free(k); free(a); free(b); free(out);
+    return 0;
+}
+
 /* Exclusive prefix sum with 32-bit wrap-around, as the test checks Pprims::scan:
  * UnitTest/main.cpp:193-199 (ans starts at 0; h[i] must equal ans; ans += cpu[i]).
  * Returns the grand total (what Pprims::scan hands back through sumOut, Pprims.cpp:164-167). */

@@ -148,6 +148,38 @@ void Pprims::radixSort(const adl::Device* device, const adl::Buffer<u32>& keys, 
     ADLASSERT(rc == ADLHIP_SUCCESS);
 }
 
+void Pprims::sortSoaWide(const adl::Device* device, void* keys, int keyBytes, void* values, int valueBytes, int n, int sortBits)
+{
+    ADLASSERT(n >= 0);
+    if (n <= 0) return;
+    ADLASSERT(enableSortOnDevice(device));   // the structure-of-arrays variants exist on the device path only
+    if (!enableSortOnDevice(device)) return;
+    ADLASSERT((sortBits & 0x3) == 0);
+    size_t tk = 0, tv = 0, wb = 0;
+    const int rcq = adlhip_radix_sort_soa_scratch_bytes(device->hip(), keyBytes, valueBytes, (size_t)n, sortBits, &tk, &tv, &wb);
+    ADLASSERT(rcq == ADLHIP_SUCCESS);
+    reserve(device, tk + tv, wb);   // scratch keys + scratch values, back to back
+    const int rc = adlhip_radix_sort_soa(device->hip(), keys, keyBytes, values, valueBytes, m_tmp->m_ptr, m_tmp->m_ptr + tk,
+                                         m_work->m_ptr, (size_t)m_work->getSize(), (size_t)n, sortBits);
+    if (rc != ADLHIP_SUCCESS) TH_LOG_ERROR("Pprims::radixSort: %s\n", adlhip_last_error());
+    ADLASSERT(rc == ADLHIP_SUCCESS);
+}
+
+void Pprims::radixSort(const adl::Device* device, const adl::Buffer<u32>& keys, const adl::Buffer<u64>& values, int n, int sortBits)
+{
+    sortSoaWide(device, keys.m_ptr, 4, values.m_ptr, 8, n, sortBits);
+}
+
+void Pprims::radixSort(const adl::Device* device, const adl::Buffer<u64>& keys, const adl::Buffer<u32>& values, int n, int sortBits)
+{
+    sortSoaWide(device, keys.m_ptr, 8, values.m_ptr, 4, n, sortBits);
+}
+
+void Pprims::radixSort(const adl::Device* device, const adl::Buffer<u64>& keys, const adl::Buffer<u64>& values, int n, int sortBits)
+{
+    sortSoaWide(device, keys.m_ptr, 8, values.m_ptr, 8, n, sortBits);
+}
+
 void Pprims::scan(const adl::Device* device, adl::Buffer<int>& dst, const adl::Buffer<int>& src, int n, u32* sumOut)
 {
     if (device == 0 || device->hip() == 0) {   // Pprims.cpp:124-127: no host fallback for scan

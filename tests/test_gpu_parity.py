@@ -884,6 +884,83 @@ def test_soa_key_value_sort(dev, pp, algo):
             kb.release(); vb.release()
 
 
+# SURVEY f3, second half: 64-bit values and 64-bit keys on separate arrays (adlhip_radix_sort_soa).  Expectation: the oracle's
+# stable 4-bit LSD passes over (key, value) arrays (oracle_radix_sort_soa; pinned to the reference's pair sort in test_oracle.py).
+V16 = np.dtype([("x", "<u4"), ("y", "<u4"), ("z", "<u4"), ("w", "<u4")])
+
+
+def _wide_values(n, vdtype, seed):
+    if vdtype == V16:
+        raw = oracle.keys_u32(4 * n, seed=seed + 1).reshape(n, 4)
+        raw[:, 0] = np.arange(n, dtype=np.uint32)          # the source index rides in the value: stability is visible
+        return raw.copy().view(V16).reshape(n)
+    if np.dtype(vdtype).itemsize == 8:
+        return (oracle.keys_u64(n, seed=seed + 1) & np.uint64(0xffffffff00000000)) | np.arange(n, dtype=np.uint64)
+    return np.arange(n, dtype=np.uint32) * np.uint32(2654435761)
+
+
+@pytest.mark.parametrize("kdtype,vdtype", [(np.uint32, np.uint64), (np.uint64, np.uint32), (np.uint64, np.uint64), (np.uint32, V16),
+                                           (np.uint64, V16), (np.uint32, np.uint32)],
+                         ids=["k32v64", "k64v32", "k64v64", "k32v128", "k64v128", "k32v32"])
+def test_soa_wide_key_value_sort(dev, pp, kdtype, vdtype):
+    rng = np.random.RandomState(23)
+    kbits = 8 * np.dtype(kdtype).itemsize
+    for n in (1, 2, 255, 4097, 70001, (1 << 20) + 5, (3 << 20) + 17):
+        gen = oracle.keys_u32 if kbits == 32 else oracle.keys_u64
+        cases = [gen(n, seed=n), rng.randint(0, 37, n).astype(kdtype)]                       # random, and many duplicates
+        if kbits == 64:
+            cases.append((rng.randint(0, 5, n).astype(np.uint64) << np.uint64(32)) | rng.randint(0, 7, n).astype(np.uint64))   # ties in either dword
+        for keys in cases:
+            vals = _wide_values(n, vdtype, n)
+            bits = kbits if n != 70001 else kbits - 12
+            kb, vb = Buffer(dev, n, kdtype), Buffer(dev, n, vdtype)
+            kb.write(keys); vb.write(vals)
+            pp.radixSortSoA(dev, kb, vb, n, bits)
+            gk, gv = kb.toHost(), vb.toHost()
+            kb.release(); vb.release()
+            wk, wv = oracle.sort_soa(keys, vals, bits)
+            assert np.array_equal(gk, wk), (n, bits)
+            assert gv.tobytes() == wv.tobytes(), (n, bits)
+
+
+def test_soa_wide_64m_u32_keys_u64_values(dev, pp):
+    """BASELINE-size check of the wide-value path: 64 Mi u32 keys with u64 values (value = source index in the low dword).
+    Size-independent properties: keys sorted, (key, index) strictly increasing among equal keys (stability), every value
+    still beside its key (value's high dword = a hash of the key), checksum of values unchanged."""
+    n = 64 << 20
+    keys = oracle.keys_u32(n, seed=77) & np.uint32(0x00ffffff)          # 16 M distinct values: ~4 duplicates per key
+    vals = ((keys.astype(np.uint64) * np.uint64(0x9E3779B1)) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    kb, vb = Buffer(dev, n, np.uint32), Buffer(dev, n, np.uint64)
+    kb.write(keys); vb.write(vals)
+    pp.radixSortSoA(dev, kb, vb, n)
+    gk, gv = kb.toHost(), vb.toHost()
+    kb.release(); vb.release()
+    assert np.all(gk[1:] >= gk[:-1])
+    assert np.array_equal(gv >> np.uint64(32), (gk.astype(np.uint64) * np.uint64(0x9E3779B1)) & np.uint64(0xffffffff))
+    idx = (gv & np.uint64(0xffffffff)).astype(np.int64)
+    same = gk[1:] == gk[:-1]
+    assert np.all(idx[1:][same] > idx[:-1][same])
+    assert int(np.bitwise_xor.reduce(gv)) == int(np.bitwise_xor.reduce(vals)) and int(idx.sum()) == n * (n - 1) // 2
+    assert np.array_equal(gk, oracle.sort_u32(keys))
+
+
+def test_soa_wide_argument_errors(dev, pp):
+    lib = _lib.load()
+    tk, tv, wb = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.adlhip_radix_sort_soa_scratch_bytes(dev._h, 2, 8, 100, 16, ctypes.byref(tk), ctypes.byref(tv), ctypes.byref(wb)) != 0
+    assert lib.adlhip_radix_sort_soa_scratch_bytes(dev._h, 4, 3, 100, 32, ctypes.byref(tk), ctypes.byref(tv), ctypes.byref(wb)) != 0
+    assert lib.adlhip_radix_sort_soa_scratch_bytes(dev._h, 4, 8, 100, 36, ctypes.byref(tk), ctypes.byref(tv), ctypes.byref(wb)) != 0
+    assert lib.adlhip_radix_sort_soa_scratch_bytes(dev._h, 8, 8, 100, 64, ctypes.byref(tk), ctypes.byref(tv), ctypes.byref(wb)) == 0
+    kb, vb = Buffer(dev, 100, np.uint64), Buffer(dev, 100, np.uint64)
+    t, w = Buffer(dev, tk.value + tv.value, np.uint8), Buffer(dev, wb.value, np.uint8)
+    # work buffer too small -> loud failure, nothing enqueued
+    assert lib.adlhip_radix_sort_soa(dev._h, kb.ptr(), 8, vb.ptr(), 8, t.ptr(), ctypes.c_void_p(t.m_ptr + tk.value), w.ptr(), 1024, 100, 64) != 0
+    assert b"work buffer too small" in lib.adlhip_last_error()
+    assert lib.adlhip_radix_sort_soa(dev._h, kb.ptr(), 8, vb.ptr(), 8, t.ptr(), ctypes.c_void_p(t.m_ptr + tk.value), w.ptr(), wb.value, 0, 64) == 0
+    for b in (kb, vb, t, w):
+        b.release()
+
+
 # ---------------------------------------------------------------------------------------------
 # Pprims::fill / copy (SURVEY f4; commented out in the reference, Pprims.cpp:31-120)
 # ---------------------------------------------------------------------------------------------
@@ -1208,7 +1285,7 @@ def test_large_keys_only_sort_two_msd_passes_and_lds_finish(dev):
         k = oracle.keys_u32(1 << 26, seed=3) >> np.uint32(8)   # the top of the size range, digits placed at bits 8..23
         assert np.array_equal(gpu_sort_u32(dev, p, k), oracle.sort_u32(k)), "below 2^24 at 64Mi"
         DeviceUtils.waitForCompletion(dev)
-        # and the automatic choice (hints included) stays correct when friendly and skewed inputs alternate
+        # and the automatic choice stays correct when friendly and skewed inputs alternate (nothing is remembered between sorts)
         dev.setParam("sort.msd2", 1)
         for i in range(6):
             k = oracle.keys_u32(n, seed=20 + i) if i % 2 == 0 else (oracle.keys_u32(n, seed=20 + i) >> np.uint32(9))
@@ -1677,7 +1754,7 @@ def test_scratch_levels_and_graceful_degradation(dev):
             check(lib.adlhip_radix_sort_u32(dev._h, data.ptr(), tmp.ptr(), work.ptr(), lean, n, 32), "sort")
             prof = dev.profile(reset=True); dev.toggleProfiling(False)
             assert set(prof) == LARGE_U32, (name, prof)
-            assert (prof["msd2_offsets"][1] > 1.0) == net, (name, prof["msd2_offsets"])
+            assert (prof["msd2_offsets"][1] > 0.3) == net, (name, prof["msd2_offsets"])
             got = data.toHost()
             assert np.array_equal(got, np.sort(k)), name
         dev.checkFault()
@@ -1731,11 +1808,16 @@ def test_narrow_second_digit_on_small_inputs(dev):
         p.close()
 
 
+def _net_stats(d):
+    return d.getParam("stat.net_runs"), d.getParam("stat.net_counting")
+
+
 def test_counting_sort_for_keys_with_few_distinct_values():
-    """Whole-key sorts of u32 / u64 keys that take at most 256 distinct values go to the counting sort (dict_kernels.hpp): the probe
-    builds a dictionary from 16 Ki sampled keys, every key is looked up and counted, the runs are written in place -- one read
-    and one write of the array.  A key the sample did not see sends the sort to the safety net inside the fill kernel (input
-    untouched until then); more than 256 values, pairs and partial sorts keep the ordinary paths.  Bit-exact against the oracle."""
+    """Whole-key sorts of u32 / u64 keys that take at most 256 distinct values: such keys cannot fit the large sort's slabs, its
+    passes give up within the first tiles and the safety net inside the offsets kernel sorts them by COUNTING (dict_kernels.hpp):
+    a dictionary from 16 Ki sampled keys, every key looked up and counted, the runs written in place.  A key the sample did not
+    see, more than 256 values, pairs and partial sorts take the net's LSD passes.  Nothing is remembered between sorts: the
+    first sort of a handle launches what the third does.  Bit-exact against the oracle."""
     rng = np.random.RandomState(11)
     n = 3000001
 
@@ -1753,13 +1835,16 @@ def test_counting_sort_for_keys_with_few_distinct_values():
                        ("256 values, skewed (the rarest has 0.1 % of the keys)",
                         vals32(256)[rng.choice(256, n, p=(1.0 / (np.arange(256) + 8)) / (1.0 / (np.arange(256) + 8)).sum())]),
                        ("low byte only", rng.randint(0, 256, n).astype(np.uint32)),
-                       ("0 and 0xffffffff", np.where(rng.rand(n) < 0.3, np.uint32(0), np.uint32(0xffffffff)).astype(np.uint32))):
+                       ("0 and 0xffffffff", np.where(rng.rand(n) < 0.3, np.uint32(0), np.uint32(0xffffffff)).astype(np.uint32)),
+                       # (advisor, round 3) the all-ones key beside ~200 other values: its hash slot must not read as free
+                       ("0xffffffff and 200 categories", np.concatenate([vals32(200), np.array([0xffffffff], dtype=np.uint32)])[rng.randint(0, 201, n)])):
         d, p = fresh()
         try:
-            for rep in range(3):   # first sort of the handle (waits for the probe), then twice on the hint
+            for rep in range(3):   # the first sort of a handle is like every other
                 got, prof = _profiled(d, lambda: gpu_sort_u32(d, p, keys))
-                assert set(prof) == {"msd2_probe", "dict_count_u32", "dict_fill_u32"}, (name, rep, prof)
+                assert set(prof) == LARGE_U32, (name, rep, prof)
                 assert np.array_equal(got, oracle.sort_u32(keys)), (name, rep)
+                assert _net_stats(d) == (rep + 1, rep + 1), (name, rep, _net_stats(d))   # the net ran, and sorted by counting
             d.checkFault()
         finally:
             p.close(); DeviceUtils.deallocate(d)
@@ -1770,44 +1855,44 @@ def test_counting_sort_for_keys_with_few_distinct_values():
     d, p = fresh()
     try:
         got, prof = _profiled(d, lambda: gpu_sort_u64(d, p, k64))
-        assert set(prof) == {"msd2_probe", "dict_count_u64", "dict_fill_u64"}, prof
+        assert "msd2_offsets" in prof and "msd2_pass1_u64" in prof, prof   # (3 M u64 keys: the cursor form)
         assert np.array_equal(got, oracle.sort_u64(k64))
-        # a value the sample cannot see (one key in three million): the count kernel misses it, the fill kernel's safety net sorts
+        assert _net_stats(d) == (1, 1)
+        # a value the sample cannot see (one key in three million): the count phase misses it, the net's LSD passes sort
         odd = k64.copy()
         odd[1234567] = np.uint64(0x0123456789abcdef)
         got, prof = _profiled(d, lambda: gpu_sort_u64(d, p, odd))
-        assert set(prof) == {"msd2_probe", "dict_count_u64", "dict_fill_u64"}, prof
-        assert prof["dict_fill_u64"][1] > 5 * prof["dict_count_u64"][1], prof   # the sort happened in there
         assert np.array_equal(got, oracle.sort_u64(odd))
-        # ... and the handle leaves the counting sort (the report said "did not fit"); results stay right whatever comes
+        assert _net_stats(d) == (2, 1)
+        # results stay right whatever comes next, and only the few-valued inputs reach the net
         for i, k in enumerate((odd, oracle.keys_u64(n, seed=3), k64, k64, oracle.keys_u64(n, seed=4), k64)):
             assert np.array_equal(gpu_sort_u64(d, p, k), oracle.sort_u64(k)), i
+        assert _net_stats(d) == (6, 4)
         d.checkFault()
     finally:
         p.close(); DeviceUtils.deallocate(d)
-    # what does not take it: 257+ values, pairs, partial sorts, the knob
+    # what is not sorted by counting: 257+ values, pairs, partial sorts, the knob
     d, p = fresh()
     try:
         many = vals32(300)[rng.randint(0, 300, n)]
-        got, prof = _profiled(d, lambda: gpu_sort_u32(d, p, many))
-        assert "dict_count_u32" not in prof, prof
-        assert np.array_equal(got, oracle.sort_u32(many))
-    finally:
-        p.close(); DeviceUtils.deallocate(d)
-    d, p = fresh()
-    try:
+        assert np.array_equal(gpu_sort_u32(d, p, many), oracle.sort_u32(many))
+        assert _net_stats(d) == (1, 0)
         few = vals32(16)[rng.randint(0, 16, n)]
         pairs = few.astype(np.uint64) | (np.arange(n, dtype=np.uint64) << np.uint64(32))
-        got, prof = _profiled(d, lambda: gpu_sort_kv(d, p, pairs))
-        assert not any(k.startswith("dict_") for k in prof), prof
-        assert np.array_equal(got, oracle.sort_kv32(pairs))
-        got, prof = _profiled(d, lambda: gpu_sort_u32(d, p, few, 24))
-        assert not any(k.startswith("dict_") for k in prof), prof
-        assert np.array_equal(got, oracle.sort_u32_bits(few, 24))
+        assert np.array_equal(gpu_sort_kv(d, p, pairs), oracle.sort_kv32(pairs))
+        assert _net_stats(d) == (2, 0)
+        assert np.array_equal(gpu_sort_u32(d, p, few, 24), oracle.sort_u32_bits(few, 24))
+        assert _net_stats(d) == (3, 0)
         d.setParam("sort.dict", 0)
-        got, prof = _profiled(d, lambda: gpu_sort_u32(d, p, few))
-        assert not any(k.startswith("dict_") for k in prof), prof
-        assert np.array_equal(got, oracle.sort_u32(few))
+        assert np.array_equal(gpu_sort_u32(d, p, few), oracle.sort_u32(few))
+        assert _net_stats(d) == (4, 0)
+        d.setParam("sort.dict", 1)
+        assert np.array_equal(gpu_sort_u32(d, p, few), oracle.sort_u32(few))
+        assert _net_stats(d) == (5, 1)
+        # keys that fit never see the net
+        u = oracle.keys_u32(n, seed=8)
+        assert np.array_equal(gpu_sort_u32(d, p, u), oracle.sort_u32(u))
+        assert _net_stats(d) == (5, 1)
     finally:
         p.close(); DeviceUtils.deallocate(d)
 
@@ -1880,34 +1965,36 @@ def test_first_sort_of_a_fresh_handle_places_its_digits_from_the_sample():
         p.close(); DeviceUtils.deallocate(d)
 
 
-def test_counting_sort_hint_then_other_keys_back_to_back():
-    """A handle on the counting sort's hint gets keys that are nothing like that, several sorts queued back to back before any
-    report can arrive: every one of them finds no dictionary and runs the safety net inside the fill kernel -- whose barrier counter
-    must start from zero each time (a net that ran before leaves it at a multiple of 256).  Found by tools/stress.py."""
+def test_few_valued_and_other_keys_back_to_back():
+    """Few-valued keys (the net's counting sort), then keys that are nothing like that, several sorts queued back to back with no
+    synchronisation in between, then few-valued keys again: every net starts its grid-barrier counter, its dictionary and its
+    counters from scratch, and no sort depends on what the one before it met.  (Round 3 steered this by a host-side hint; a net
+    that started from a stale barrier counter was found by tools/stress.py then.)"""
     n = (1 << 22) + 321
     d = DeviceUtils.allocate()
     set_algo(d, (-1, 8, -1))
     p = Pprims()
     try:
         few = (oracle.keys_u32(n, seed=1) % np.uint32(5)) * np.uint32(0x01010101)
-        got, prof = _profiled(d, lambda: gpu_sort_u32(d, p, few))
-        assert "dict_fill_u32" in prof, prof
-        assert np.array_equal(got, oracle.sort_u32(few))
+        assert np.array_equal(gpu_sort_u32(d, p, few), oracle.sort_u32(few))
+        assert _net_stats(d) == (1, 1)
+        nets = 1
         for kind in ("u32", "u64"):
             keys = oracle.keys_u32(n, seed=2) if kind == "u32" else oracle.keys_u64(n, seed=2)
-            bufs = [Buffer(d, n, keys.dtype) for _ in range(4)]
-            for b in bufs:
-                b.write(keys)
+            fk = few if kind == "u32" else few.astype(np.uint64) * np.uint64(0x100000001)
+            bufs = [Buffer(d, n, keys.dtype) for _ in range(6)]
+            for i, b in enumerate(bufs):
+                b.write(fk if i in (1, 4) else keys)
             DeviceUtils.waitForCompletion(d)
-            # re-arm the hint (the uniform sorts below will have dropped it)
-            assert np.array_equal(gpu_sort_u32(d, p, few), oracle.sort_u32(few))
-            assert np.array_equal(gpu_sort_u32(d, p, few), oracle.sort_u32(few))
-            for b in bufs:                        # four sorts queued without a synchronisation in between
+            for b in bufs:                        # six sorts queued without a synchronisation in between
                 (p.radixSort if kind == "u32" else p.radixSort64)(d, b, n)
             want = oracle.sort_u32(keys) if kind == "u32" else oracle.sort_u64(keys)
+            wantf = oracle.sort_u32(fk) if kind == "u32" else oracle.sort_u64(fk)
             for i, b in enumerate(bufs):
-                assert np.array_equal(b.toHost(), want), (kind, i)
+                assert np.array_equal(b.toHost(), wantf if i in (1, 4) else want), (kind, i)
                 b.release()
+            nets += 2
+            assert _net_stats(d) == (nets, nets)
         d.checkFault()
     finally:
         p.close(); DeviceUtils.deallocate(d)
@@ -1928,21 +2015,19 @@ def test_probe_sample_positions_stay_inside_the_array(dev):
         check(lib.adlhip_selftest_probe_positions(dev._h, n, ctypes.byref(hi), ctypes.byref(bad)), "probe positions")
         assert bad.value == 0 and hi.value < n, (n, hi.value, bad.value)
         assert hi.value >= n - 2 * (n // 16384) - 2, (n, hi.value)   # the last cell is sampled too
-    # the sorts that raised the fault: fresh handles, so the probe runs
-    for kind, n, shift in (("u32", 7726351, 16), ("u64", 730669, 10)):
+    # the sizes that raised the fault, on keys that send the sort to its net -- where the samples are read since round 4
+    for kind, n in (("u32", 7726351), ("u64", 730669)):
         d = DeviceUtils.allocate()
         set_algo(d, (-1, 8, -1))
         p = Pprims()
         try:
             if kind == "u32":
-                k = oracle.keys_u32(n, seed=2225) >> np.uint32(shift)
-                got, prof = _profiled(d, lambda: gpu_sort_u32(d, p, k))
-                assert np.array_equal(got, oracle.sort_u32(k))
+                k = (oracle.keys_u32(n, seed=2225) >> np.uint32(29)) * np.uint32(0x01020304)
+                assert np.array_equal(gpu_sort_u32(d, p, k), oracle.sort_u32(k))
             else:
-                k = oracle.keys_u64(n, seed=77) >> np.uint64(shift)
-                got, prof = _profiled(d, lambda: gpu_sort_u64(d, p, k))
-                assert np.array_equal(got, oracle.sort_u64(k))
-            assert "msd2_probe" in prof, prof
+                k = (oracle.keys_u64(n, seed=77) >> np.uint64(61)) * np.uint64(0x0102030405060708)
+                assert np.array_equal(gpu_sort_u64(d, p, k), oracle.sort_u64(k))
+            assert _net_stats(d) == (1, 1)
             d.checkFault()
         finally:
             p.close(); DeviceUtils.deallocate(d)

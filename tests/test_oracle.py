@@ -129,3 +129,39 @@ def test_splitmix_generator_is_index_addressable():
     p = oracle.pairs_kv32(100, seed=123, first_index=50)
     assert np.array_equal((p >> 32).astype(np.uint32), np.arange(50, 150, dtype=np.uint32))
     assert np.array_equal((p & 0xffffffff).astype(np.uint32), oracle.keys_u32(100, 123, 50))
+
+
+def test_soa_oracle_is_the_pair_sort_on_separate_arrays():
+    """oracle_radix_sort_soa (separate key / value arrays, wide values) pinned: for 4-byte keys and values it must
+    give what the restated pair sort gives on the packed pairs -- which the golden vectors and libref.so pin to the
+    reference's RadixSort::sort(SortData*) --, and for every width what numpy's stable argsort gives."""
+    rng = np.random.RandomState(5)
+    for n in (0, 1, 2, 257, 4099, 100003):
+        for keys in (oracle.keys_u32(n, seed=n + 1), rng.randint(0, 9, n).astype(np.uint32)):
+            vals = (np.arange(n, dtype=np.uint32) * np.uint32(2654435761)) ^ np.uint32(0x5bd1e995)
+            k, v = oracle.sort_soa(keys, vals)
+            pairs = keys.astype(np.uint64) | (vals.astype(np.uint64) << np.uint64(32))
+            want = oracle.sort_kv32(pairs)
+            assert np.array_equal(k, (want & np.uint64(0xffffffff)).astype(np.uint32))
+            assert np.array_equal(v, (want >> np.uint64(32)).astype(np.uint32))
+            if oracle.have_ref() and n:
+                ref = oracle.ref_sort_kv32(pairs)
+                assert np.array_equal(k, (ref & np.uint64(0xffffffff)).astype(np.uint32))
+                assert np.array_equal(v, (ref >> np.uint64(32)).astype(np.uint32))
+            for bits in (4, 12, 20, 28):
+                k, v = oracle.sort_soa(keys, vals, bits)
+                want = oracle.sort_e64_bits(pairs, bits)
+                assert np.array_equal(k, (want & np.uint64(0xffffffff)).astype(np.uint32))
+                assert np.array_equal(v, (want >> np.uint64(32)).astype(np.uint32))
+    for kdt, bits_list in ((np.uint32, (32, 16)), (np.uint64, (64, 40, 32, 8))):
+        for vdt in (np.uint32, np.uint64, np.dtype([("a", "<u8"), ("b", "<u8")])):
+            n = 50021
+            keys = (rng.randint(0, 1 << 30, n).astype(np.uint64) * np.uint64(0x100000001b3)).astype(kdt) >> kdt(3)
+            keys[::7] = keys[3]                                        # duplicates
+            vals = np.zeros(n, dtype=vdt)
+            vals.view(np.uint8).reshape(n, -1)[:] = rng.randint(0, 256, (n, np.dtype(vdt).itemsize)).astype(np.uint8)
+            for bits in bits_list:
+                mask = kdt((1 << bits) - 1) if bits < 64 else kdt(0xffffffffffffffff)
+                order = np.argsort(keys & mask, kind="stable")
+                k, v = oracle.sort_soa(keys, vals, bits)
+                assert np.array_equal(k, keys[order]) and v.tobytes() == vals[order].tobytes(), (kdt, vdt, bits)
