@@ -61,12 +61,18 @@ __device__ __forceinline__ uint32_t dict_build(const unsigned long long (&smp)[P
         }
         uint32_t h = (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> 53);   // 11 bits
         for (int step = 0; step < 2048; ++step) {
-            const unsigned long long old = atomicCAS(&s_tab[h], kDictEmpty, v);
-            if (old == kDictEmpty) {
-                atomicAdd(&s_cnt, 1u);
-                break;
-            }
+            // look before the compare-and-swap: once a value sits in the table every later sample of it ends here with a plain read
+            // (few values: 64 lanes' compare-and-swaps on a handful of LDS words were served one after the other, ~50 us of the build)
+            unsigned long long old = __hip_atomic_load(&s_tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (old == v) break;
+            if (old == kDictEmpty) {
+                old = atomicCAS(&s_tab[h], kDictEmpty, v);
+                if (old == kDictEmpty) {
+                    atomicAdd(&s_cnt, 1u);
+                    break;
+                }
+                if (old == v) break;
+            }
             h = (h + 1u) & 2047u;
         }
     }

@@ -106,20 +106,21 @@ __device__ __forceinline__ void dict_count_range(const E* __restrict__ src, uint
             else atomicAdd(&my[ix], 1u);
         }
     };
-    // whole waves stay together (the vote above); four 16-byte loads in flight per lane
+    // whole waves stay together (the vote above); U 16-byte loads in flight per lane
+    constexpr int U = 8;
     const uint32_t step = gridDim.x * (uint32_t)NT;
-    for (uint32_t i0 = blockIdx.x * (uint32_t)NT; i0 < nvec; i0 += 4u * step) {
-        Vec v[4];
-        bool act[4];
+    for (uint32_t i0 = blockIdx.x * (uint32_t)NT; i0 < nvec; i0 += (uint32_t)U * step) {
+        Vec v[U];
+        bool act[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = i0 + (uint32_t)u * step + (uint32_t)tid;
-            act[u] = i0 + (uint32_t)u * step < nvec && i < nvec;
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = (uint64_t)i0 + (uint64_t)u * step + (uint32_t)tid;
+            act[u] = i < nvec;
             if (act[u]) v[u] = vsrc[i];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (i0 + (uint32_t)u * step < nvec) {   // (uniform over the workgroup)
+        for (int u = 0; u < U; ++u) {
+            if ((uint64_t)i0 + (uint64_t)u * step < nvec) {   // (uniform over the workgroup)
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) one(act[u] ? v[u].v[k] : E(0), act[u]);
             }

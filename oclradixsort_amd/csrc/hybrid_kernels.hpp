@@ -183,6 +183,10 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
         // ---- scatter this workgroup's tiles, carrying per-digit offsets from tile to tile ------------------------------
         {
             const uint32_t tot_d = tid < 256 ? totals[tid] : 0u;
+            // every key has the same digit here (a constant byte: small ranges, few-valued keys): the pass would move nothing
+            // (the next pass's count phase writes this workgroup's own table column only, and nobody rewrites the totals before
+            // the next barrier, so the barrier that ends a pass is not needed either)
+            if (__syncthreads_or(tid < 256 && tot_d == n)) continue;
             const uint32_t base_d = block_excl_scan_u32<NT>(tot_d, s_wsum, nullptr);
             uint32_t carry = tid < 256 ? base_d + table[(size_t)tid * wgs + wg] : 0u;
             const AosIO<E> io{src, dst};

@@ -135,8 +135,8 @@ __global__ __launch_bounds__(NT, WPE) void msd_scatter_persist_kernel(BucketPass
     if (a.zero_me && blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.zero_me, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // A run that did not fit its slab has raised the flag: the sort's result will come from the safety net (hybrid_kernels.hpp
-    // net_sort), whatever is written from here on is never read.  The second pass leaves at once; the first looks at the flag once
-    // per tile (below) -- keys that are all equal overflow a slab within the first per cent of the input.
+    // net_sort), whatever is written from here on is never read.  The second pass leaves at once when the first has raised it; both
+    // look at the flag once per tile (below) -- keys that are all equal overflow a slab within the first per cent of the input.
     if constexpr (PASS >= 2) {
         if (__hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     }
@@ -250,8 +250,7 @@ __global__ __launch_bounds__(NT, WPE) void msd_scatter_persist_kernel(BucketPass
         const bool has_next = ticket_n < t_end;
         // the overflow flag, requested with the next tile's keys and looked at where those are waited for (one more countable
         // vector-memory operation in front of this tile's stores: the wait at the bottom stays s_waitcnt vmcnt(K))
-        uint32_t give_up = 0u;
-        if constexpr (PASS == 1) give_up = __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t give_up = __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (has_next) {
             tn = tile_of(ticket_n);
             load_tile(tn, nxt);   // in flight through the whole body below
@@ -401,9 +400,7 @@ __global__ __launch_bounds__(NT, WPE) void msd_scatter_persist_kernel(BucketPass
             }
         }
         if (!has_next) break;
-        if constexpr (PASS == 1) {
-            if (give_up) break;   // (uniform: every lane loaded the same word)
-        }
+        if (give_up) break;   // (uniform: every lane loaded the same word)
         // (no barrier here: the next tile touches s_elems / s_goff / the positions only behind ITS first barrier, which every wave
         // reaches after its write-out; the wave's own counters are read by the other waves before this tile's second barrier)
         // the prefetched keys become the current ones: s_waitcnt vmcnt(K) -- the K stores above stay in flight

@@ -284,3 +284,86 @@ def test_world_size_must_be_power_of_two():
     k = oracle.keys_u32(1000, 3)
     got = s.sort(torch.from_numpy(k.view(np.int32).copy()))
     assert np.array_equal(got.numpy().view(np.uint32), oracle.sort_u32(k))
+
+
+# ---- world 4 and 8 (review, round 3: the G = 8 split arithmetic ran only as single-process unit checks) ---------------------------
+def _worker_g(rank, world, port, sizes, kind, out_dir, balance, pairs):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from oclradixsort_amd.dist import ShardedRadixSort
+        n = sizes[rank]
+        first = sum(sizes[:rank])
+        keys = oracle.keys_u32(n, seed=91, first_index=first)
+        if kind == "skewed":          # 90 % of the keys in one eighth of the key range
+            keys = np.where(np.arange(n) % 10 != 0, keys >> np.uint32(3), keys).astype(np.uint32)
+        elif kind == "one_top_byte":  # every key under ONE top byte: one rank receives everything, the others nothing
+            keys = ((keys >> np.uint32(8)) | np.uint32(0x37000000)).astype(np.uint32)
+        elif kind == "two_top_bytes":  # two populated byte values, 3 : 1
+            keys = np.where(np.arange(n) % 4 != 0, (keys >> np.uint32(8)) | np.uint32(0x11000000), (keys >> np.uint32(8)) | np.uint32(0xee000000)).astype(np.uint32)
+        if pairs:
+            keys = (keys & np.uint32(0xff00000f)).astype(np.uint64) | ((np.arange(n, dtype=np.uint64) + np.uint64(first)) << np.uint64(32))
+        sorter = ShardedRadixSort(NumpyBackend(), balance=balance)
+        got = sorter.sort(torch.from_numpy(keys.view(np.int64 if pairs else np.int32).copy()))
+        np.save(os.path.join(out_dir, "out_%d.npy" % rank), got.numpy().view(np.uint64 if pairs else np.uint32))
+        np.save(os.path.join(out_dir, "in_%d.npy" % rank), keys)
+        if balance:
+            np.save(os.path.join(out_dir, "bounds_%d.npy" % rank), sorter.last_bounds.numpy())
+        send, recv = sorter.last_splits
+        assert sum(send) == n and sum(recv) == got.numel() and len(send) == world and len(recv) == world
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("kind,balance,pairs", [("uniform", True, False), ("skewed", True, False), ("skewed", False, False),
+                                                  ("one_top_byte", True, False), ("two_top_bytes", True, True), ("uniform", True, True)],
+                         ids=["uniform", "skewed-balanced", "skewed-fixed", "one-top-byte", "two-top-bytes-pairs", "uniform-pairs"])
+def test_sharded_sort_world_4_and_8_gloo(tmp_path, world, kind, balance, pairs):
+    """The exchange driver at G = 4 and 8: ragged shards (one source rank holds NOTHING), splitters at G - 1 boundaries, ranks
+    that receive nothing, pairs stable in (source rank, position) order.  Rank order must be key order, bit-exact vs the oracle."""
+    import oracle
+    sizes = [20011 + 997 * r for r in range(world)]
+    sizes[world // 2] = 0                                         # a rank with an empty shard
+    mp.spawn(_worker_g, args=(world, _free_port(), sizes, kind, str(tmp_path), balance, pairs), nprocs=world, join=True)
+    ins = [np.load(tmp_path / ("in_%d.npy" % r)) for r in range(world)]
+    outs = [np.load(tmp_path / ("out_%d.npy" % r)) for r in range(world)]
+    allin = np.concatenate(ins)
+    want = oracle.sort_kv32(allin) if pairs else oracle.sort_u32(allin)
+    assert np.array_equal(np.concatenate(outs), want)
+    key = (lambda o: (o & np.uint64(0xffffffff)).astype(np.uint32)) if pairs else (lambda o: o)
+    total = sum(o.size for o in outs)
+    if balance:
+        bs = [np.load(tmp_path / ("bounds_%d.npy" % r)) for r in range(world)]
+        for b in bs[1:]:
+            assert np.array_equal(b, bs[0])                       # every rank computed the same splitters
+        b = bs[0]
+        assert b.shape == (world + 1,) and b[0] == 0 and b[-1] == 256 and np.all(np.diff(b) >= 0)
+        for r, o in enumerate(outs):
+            top = key(o) >> np.uint32(24)
+            assert o.size == 0 or ((top >= b[r]) & (top < b[r + 1])).all()
+        hist = np.bincount((key(allin) >> np.uint32(24)).astype(np.int64), minlength=256)
+        assert max(o.size for o in outs) <= total / world + 2 * hist.max() + 1   # choose_splitters' bound
+        if kind == "one_top_byte":
+            assert sorted(o.size for o in outs)[-1] == total and sum(1 for o in outs if o.size == 0) == world - 1
+        if kind == "uniform":
+            assert max(o.size for o in outs) <= 1.25 * total / world
+    else:
+        lg = world.bit_length() - 1
+        for r, o in enumerate(outs):
+            assert o.size == 0 or ((key(o) >> np.uint32(32 - lg)) == r).all()
+
+
+def test_pipelined_sort_stream_world4_gloo(tmp_path):
+    """sort_stream at G = 4: batches of changing size (one empty) and skew through the two-stage pipeline."""
+    import oracle
+    world = 4
+    sizes = [20009, 500, 0, 26001, 14141]
+    mp.spawn(_stream_worker, args=(world, _free_port(), sizes, str(tmp_path)), nprocs=world, join=True)
+    for b in range(len(sizes)):
+        ins = [np.load(tmp_path / ("in_%d_%d.npy" % (b, r))) for r in range(world)]
+        outs = [np.load(tmp_path / ("out_%d_%d.npy" % (b, r))) for r in range(world)]
+        assert np.array_equal(np.concatenate(outs), oracle.sort_u32(np.concatenate(ins))), "batch %d" % b

@@ -2031,3 +2031,22 @@ def test_probe_sample_positions_stay_inside_the_array(dev):
             d.checkFault()
         finally:
             p.close(); DeviceUtils.deallocate(d)
+
+
+def test_config4_memory_budget_on_one_device():
+    """BASELINE config #4 per GPU (review, round 3, item 7c): HipBackend.reserve(2^27) -- receive slots with 25 % head-room and
+    partition slots, three deep, plus both stages' level-1 scratch -- must fit one MI355X many times over.  Measured on the device:
+    what torch and the library actually hold afterwards."""
+    import torch
+    from oclradixsort_amd.dist import HipBackend
+    torch.cuda.synchronize()
+    free0, total = torch.cuda.mem_get_info()
+    be = HipBackend()
+    be.reserve(1 << 27)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    used = free0 - free1
+    assert used < 16 * (1 << 30), used            # measured: about 6 GiB of 288 GB
+    assert used > 3 * (int(1.25 * (1 << 27)) * 4)  # (at least the three receive slots: the reservation really happened)
+    assert total > 200 * (1 << 30)
+    be.close() if hasattr(be, "close") else None

@@ -13,6 +13,7 @@ h = i * np.uint32(2654435761)
 kinds = {
     "all_equal": np.full(n, 0x12345678, dtype=np.uint32),
     "16_values": (h >> np.uint32(28)) * np.uint32(0x11111111),
+    "256_values": ((h >> np.uint32(24)) * np.uint32(0x01010101)) ^ np.uint32(0x5a5a0000),
     "4096_values": (h >> np.uint32(20)) * np.uint32(0x00100801),
     "heavy_top_byte": np.where(i % 10 != 0, (h >> np.uint32(8)) | np.uint32(0x37000000), h * np.uint32(40503)).astype(np.uint32),
 }
