@@ -389,6 +389,7 @@ def main():
                 lib.adlhip_radix_sort_scratch_bytes(d._h, 0, n, ct.byref(tb), ct.byref(wb))
                 pw = Buffer(d, wb.value + wb.value // 8, np.uint8)
                 pt = Buffer(d, 256, np.uint32)
+                d.setParam("partition.lookback", 0)   # the three-kernel form: its first kernel is the plain digit histogram
                 d.toggleProfiling(True)
                 d.profile(reset=True)
                 for r in range(8):
@@ -398,6 +399,7 @@ def main():
                         raise RuntimeError("adlhip_partition_top_byte_u32 failed")
                 pprof = d.profile(reset=True)
                 d.toggleProfiling(False)
+                d.setParam("partition.lookback", 1)
                 pw.release()
                 pt.release()
                 ck = [k for k in pprof if k.startswith("count_")]

@@ -315,24 +315,34 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      (pairs; keys with a constant top byte: byte histograms, stable MSD pass, LDS finish)
  *                      instead of the per-digit passes.  Keys that do not fit the buckets are detected on the
  *                      device and sorted by a cooperative LSD sort inside the same launches (correct, slower);
- *                      the handle then steers later sorts by asynchronous hints (speed only; results never
- *                      depend on them).  2 / 3 force the two- / three-launch form (tests)
- *   "sort.msd2"        1 [default] / 0: sorts of 2 Mi .. 1088 Mi u32 keys, 2 Mi .. 260 Mi u64 keys and 1 Mi .. 260 Mi pairs on 16 or
+ *                      the handle then steers later sorts of this size class by asynchronous hints (speed only;
+ *                      results never depend on them).  2 / 3 force the two- / three-launch form (tests)
+ *   "sort.msd2"        1 [default] / 0: sorts of 2 Mi .. 1088 Mi u32 keys, 100 K .. 260 Mi u64 keys and 1 Mi .. 260 Mi pairs on 16 or
  *                      more bits take two MSD passes into slabs of the work buffer plus one finish in LDS (six moves of
  *                      every element instead of nine); where the two digits sit is chosen on the device from a sample of
  *                      the keys (inside the low sort_bits bits).  Whole keys: runs are placed with atomic cursors (equal keys
- *                      are indistinguishable), from 96 Mi u32 / 48 Mi u64 keys the first (or both) passes by look-back;
- *                      pairs and sorts on part of the key: by look-back, stably.  Keys that do not fit the slabs are
- *                      detected on the device and sorted by a cooperative LSD sort inside the same launches (correct,
- *                      slower).  A handle's first sort looks at a sample of its keys and waits for the verdict (one stream
- *                      synchronisation per handle); afterwards asynchronous reports steer it (speed only; results never
- *                      depend on them).  2 forces the path from 1 Mi elements (tests), 3 / 4 / 5 force its stable /
- *                      cursor / hybrid form where it applies
+ *                      are indistinguishable), from 192 Mi u32 / 48 Mi u64 keys the first (or both) passes by look-back;
+ *                      pairs and sorts on part of the key: by look-back, stably.  The slabs give every bucket the same room:
+ *                      keys whose density varies by more than ~45 % over their range, or that repeat a few values, do not fit.
+ *                      That is detected on the device -- the passes stop at their next tile -- and the sort's own offsets
+ *                      kernel then sorts the untouched input: by counting if the keys take at most 256 values ("sort.dict"),
+ *                      else by four (eight) LSD passes with grid-wide barriers between their phases (64 Mi u32 keys: 0.37 ms
+ *                      and 1.4 ms instead of 0.32; profiles/r4_distributions.txt).  Nothing is reported to the host and
+ *                      nothing is remembered between sorts: a sort entry point never waits, and the first sort of an input
+ *                      takes the time its hundredth does.  (Rounds 2-3 kept such keys off this path by a probe launch,
+ *                      pinned-memory reports and a back-off counter in the handle; all of that is gone.)
+ *                      2 forces the path from 1 Mi elements (tests), 3 / 4 / 5 force its stable / cursor / hybrid form
  *   "sort.binfinish"   1 [default]: whole u64 keys finish their segments by one counting pass on the top bits below the
  *                      digits + whole-key compares inside the bins (where a segment holds ~384 keys and more); 0: the
  *                      wave-per-segment LSD finish; 2: always, u32 keys too (tests, measurements)
- *   "sort.dict"        1 [default] / 0: whole-key sorts of more than 2 Mi u32 / u64 keys that take at most 256 distinct values
- *                      (the sample's verdict) are sorted by counting: dictionary, one read, one write
+ *   "sort.dict"        1 [default] / 0: the large sort's safety net first samples 16 Ki keys; if they take at most 256 distinct
+ *                      values (whole-key sorts of u32 / u64 keys only: equal keys are interchangeable) it sorts by counting
+ *                      -- dictionary, one read, one write -- and falls through to its LSD passes when a key misses the dictionary
+ *   "partition.lookback" 1 [default] / 0: adlhip_partition_* on 24 MiB of data and more, with a work buffer of the sort's
+ *                      full-speed size, is one look-back pass (histogram + chain kernel of the one-sweep path) instead of
+ *                      count -> scan -> scatter; the same output bit for bit
+ *   "stat.net_runs", "stat.net_counting" (read-only; reading waits for the stream) how often the large sort's safety net has run
+ *                      on this handle, and how often it sorted by counting
  *   "debug.resident_wgs" workgroups the device certainly keeps resident at once (asked of the runtime at creation); the
  *                      paths whose safety nets hold a grid-wide barrier over 256 workgroups are taken only when it is
  *                      >= 256.  Setting it stands in for a small partition (tests); 0 = ask the device again

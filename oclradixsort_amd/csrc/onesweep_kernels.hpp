@@ -139,9 +139,9 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
         auto bin_of = [&](E x, int p) -> uint32_t {
             const int sb = desc.start_bit[p];
             const int nb = desc.nbits[p];
-            // pass 0 (starts at bit 0; the chain is workgroup-uniform): bin = chain * 2^nb + digit.  With the
-            // uniform chain in the LOW bits every lane would hit one of 4 LDS banks.
-            if (p == 0) return (chain0 << nb) | ((uint32_t)x & ((1u << nb) - 1u));
+            // pass 0 (the chain is workgroup-uniform; it starts at bit 0 in a sort, at bit 24 as the one-pass MSB partition):
+            // bin = chain * 2^nb + digit.  With the uniform chain in the LOW bits every lane would hit one of 4 LDS banks.
+            if (p == 0) return (chain0 << nb) | ((uint32_t)(x >> sb) & ((1u << nb) - 1u));
             // p >= 1: bin = digit * kChains + chain = the nb + kChainBits contiguous key bits from sb - kChainBits (one v_bfe_u32)
             uint32_t v;
             if constexpr (sizeof(E) == 8) v = (uint32_t)((uint64_t)x >> (sb - kChainBits));
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
             auto mask_of = [&](int p) -> K {
                 const int sb = desc.start_bit[p];
                 const int nb = desc.nbits[p];
-                return (p == 0) ? (K)((1u << nb) - 1u) : ((K)((1u << (nb + kChainBits)) - 1u) << (sb - kChainBits));
+                return (p == 0) ? ((K)((1u << nb) - 1u) << sb) : ((K)((1u << (nb + kChainBits)) - 1u) << (sb - kChainBits));
             };
             auto plain = [&](int p, uint32_t off) {
 #pragma unroll
@@ -629,6 +629,15 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTab
         g_stamp_buf[(size_t)tile * 16 + 14] = rt;
     }
 #endif
+}
+
+// totals[d] = sum over the 16 chains of pass 0's joint histogram (chain-major: joint[chain * 256 + digit]; 8-bit digits)
+__global__ __launch_bounds__(256) void fold_joint_kernel(const uint32_t* __restrict__ joint, uint32_t* __restrict__ totals)
+{
+    uint32_t s = 0u;
+#pragma unroll
+    for (int c = 0; c < kChains; ++c) s += joint[c * 256 + (int)threadIdx.x];
+    totals[threadIdx.x] = s;
 }
 
 // counts[k] = number of keys whose top log2(num_buckets) bits equal k, from the 256 top-byte totals.

@@ -2050,3 +2050,47 @@ def test_config4_memory_budget_on_one_device():
     assert used > 3 * (int(1.25 * (1 << 27)) * 4)  # (at least the three receive slots: the reservation really happened)
     assert total > 200 * (1 << 30)
     be.close() if hasattr(be, "close") else None
+
+
+def test_partition_top_byte_one_lookback_pass_equals_three_kernels(dev):
+    """The multi-GPU send side (review, round 3, item 7b): from 24 MiB of data the top-byte partition is ONE look-back pass (the
+    one-sweep path's histogram + chain kernel with a one-pass plan) instead of count -> scan -> scatter.  Both are stable, so the
+    output and the 256 totals must be the same bit for bit -- checked against numpy's stable argsort and against the three-kernel
+    form ("partition.lookback" = 0), for keys and for pairs, uniform and skewed, with the kernel names asserted."""
+    lib = _lib.load()
+    for kind, n in (("u32", (1 << 23) + 4321), ("kv32", (1 << 22) + 77), ("u32", (1 << 26) + 5)):
+        pairs = kind == "kv32"
+        dtype = np.uint64 if pairs else np.uint32
+        for skew in (False, True):
+            k = oracle.keys_u32(n, seed=31 + n % 7)
+            if skew:
+                k = np.where(np.arange(n) % 10 != 0, k >> np.uint32(3), k).astype(np.uint32)
+            host = (k.astype(np.uint64) | (np.arange(n, dtype=np.uint64) << np.uint64(32))) if pairs else k
+            order = np.argsort(k >> np.uint32(24), kind="stable")
+            want, want_tot = host[order], np.bincount((k >> np.uint32(24)).astype(np.int64), minlength=256).astype(np.uint32)
+            tb, wb = ctypes.c_size_t(), ctypes.c_size_t()
+            check(lib.adlhip_radix_sort_scratch_bytes(dev._h, 1 if pairs else 0, n, ctypes.byref(tb), ctypes.byref(wb)), "scratch")
+            src, dst, tot, work = Buffer(dev, n, dtype), Buffer(dev, n, dtype), Buffer(dev, 256, np.uint32), Buffer(dev, wb.value, np.uint8)
+            src.write(host)
+            fn = lib.adlhip_partition_top_byte_kv32 if pairs else lib.adlhip_partition_top_byte_u32
+            try:
+                for lookback in (1, 0):
+                    dev.setParam("partition.lookback", lookback)
+                    dst.clear(); tot.clear()
+                    dev.toggleProfiling(True); dev.profile(reset=True)
+                    check(fn(dev._h, src.ptr(), dst.ptr(), tot.ptr(), work.ptr(), wb.value, n), "partition")
+                    prof = dev.profile(reset=True); dev.toggleProfiling(False)
+                    names = set(prof)
+                    if lookback:
+                        assert any(x.startswith("onesweep_") for x in names) and "os_fold_totals" in names, names
+                    else:
+                        assert any(x.startswith("scatter_") for x in names) and not any(x.startswith("onesweep_") for x in names), names
+                    assert np.array_equal(dst.toHost(), want), (kind, n, skew, lookback)
+                    assert np.array_equal(tot.toHost(), want_tot), (kind, n, skew, lookback)
+                    assert np.array_equal(src.toHost(), host)      # the input is left intact
+                dev.checkFault()
+            finally:
+                dev.toggleProfiling(False)
+                dev.setParam("partition.lookback", 1)
+                for b in (src, dst, tot, work):
+                    b.release()
