@@ -5,7 +5,7 @@ result copied back, full oracle comparison for the smaller ones), fault word che
 is followed -- while later sorts are already queued -- by the LDS-order self-test on a SECOND handle (the hardware
 behaviour "sort.rank" = 1 rests on, adlhip_selftest_lds_order), and one size class reaches past 64 Mi keys (the
 pointer-store write-out).  Half of the sorts take the automatic choice (mid-size sort, large sort with its look-back /
-cursor passes, hints and safety net), with "sort.msd2" forced on for some and keys shifted down by a random number of bits.
+cursor passes and the safety net inside its offsets kernel), with "sort.msd2" forced on for some and keys shifted down by a random number of bits.
    python tools/stress.py [--seconds 60]"""
 import argparse, os, sys, time
 import numpy as np
@@ -29,7 +29,7 @@ def checks(a):
     return int(a64.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(a64)) if a.size else 0
 while time.time() < t_end and it < args.stop_after:
     it += 1
-    kind = rng.choice(["u32", "kv", "u64", "soa"])
+    kind = rng.choice(["u32", "kv", "u64", "soa", "soaw"])
     n = int(2 ** rng.uniform(10, 25.5)) + int(rng.randint(0, 1000))
     if it % 7 == 0: n = int(2 ** rng.uniform(21, 26.3))   # more of the large sort's range
     if kind == "u32" and it % 23 == 0: n = (1 << 26) + int(rng.randint(1, 1 << 22))     # past 256 MiB: pointer stores
@@ -37,8 +37,8 @@ while time.time() < t_end and it < args.stop_after:
     algo = int(rng.choice([0, 0, 1, -1, -1, -1])); bits = int(rng.choice([8, 8, 8, 4])); tile = int(rng.choice([-1, -1, 0, 1, 2, 5]))
     if algo < 0: bits, tile = 8, -1   # what the automatic paths run with
     d.setParam("sort.algo", algo); d.setParam("sort.digit_bits", bits); d.setParam("sort.tile", tile)
-    d.setParam("sort.msd2", int(rng.choice([1, 1, 1, 2, 3, 4, 5])))   # automatic (hints, probe, counting sort) or a forced form
-    dist = rng.choice(["uniform", "lowbits", "fewvals", "sortedish", "shifted", "shifted"])
+    d.setParam("sort.msd2", int(rng.choice([1, 1, 1, 2, 3, 4, 5])))   # automatic or a forced form
+    dist = rng.choice(["uniform", "lowbits", "fewvals", "sortedish", "shifted", "shifted", "heavy", "vals4096"])
     shift = int(rng.randint(1, 20))
     msd2_mode = d.getParam("sort.msd2")
     if it < skip_before:   # replay: only the draws of the generator (they do not depend on any result)
@@ -47,8 +47,10 @@ while time.time() < t_end and it < args.stop_after:
             else: rng.randint(1, 4)
         continue
     if verbose: print("it %d %s n=%d algo=%d bits=%d tile=%d msd2=%d dist=%s shift=%d" % (it, kind, n, algo, bits, tile, msd2_mode, dist, shift), flush=True)
-    if kind in ("u32", "soa", "kv"):
+    if kind in ("u32", "soa", "kv", "soaw"):
         k = oracle.keys_u32(n, seed=it)
+        if dist == "heavy": k = np.where(np.arange(n) % 10 != 0, (k >> np.uint32(8)) | np.uint32(0x37000000), k).astype(np.uint32)
+        elif dist == "vals4096": k = (k >> np.uint32(20)) * np.uint32(0x00100801)
         if dist == "lowbits": k &= np.uint32(0xffff)
         elif dist == "fewvals": k = (k % np.uint32(5)) * np.uint32(0x01010101)
         elif dist == "sortedish": k = np.sort(k)
@@ -84,6 +86,19 @@ while time.time() < t_end and it < args.stop_after:
         p.radixSortSoA(d, kb, vb, n); ok, ov = kb.toHost(), vb.toHost(); kb.release(); vb.release()
         assert np.all(ok[1:] >= ok[:-1]); same = ok[1:] == ok[:-1]
         assert np.all(ov[1:][same] > ov[:-1][same]) and np.array_equal(k[ov], ok), (it, kind, n, algo, bits, tile, dist)
+    elif kind == "soaw":   # wide values / 64-bit keys on separate arrays (adlhip_radix_sort_soa): index sort + gather
+        n = min(n, 1 << 23)
+        k = k[:n]
+        kd = np.uint64 if it % 2 else np.uint32
+        vd = [np.uint64, np.uint32, np.dtype([("a", "<u8"), ("b", "<u8")])][it % 3]
+        keys = k.astype(np.uint64) * np.uint64(0x100000001) >> np.uint64(it % 29) if kd == np.uint64 else k
+        vals = np.zeros(n, dtype=vd)
+        vals.view(np.uint32).reshape(n, -1)[:, 0] = np.arange(n, dtype=np.uint32)
+        kb = Buffer(d, n, kd); vb = Buffer(d, n, vd); kb.write(keys); vb.write(vals)
+        p.radixSortSoA(d, kb, vb, n); ok, ov = kb.toHost(), vb.toHost(); kb.release(); vb.release()
+        idx = ov.view(np.uint32).reshape(n, -1)[:, 0].astype(np.int64)
+        assert np.all(ok[1:] >= ok[:-1]); same = ok[1:] == ok[:-1]
+        assert np.all(idx[1:][same] > idx[:-1][same]) and np.array_equal(keys[idx], ok), (it, kind, n, kd, vd, dist)
     else:
         k64 = oracle.keys_u64(n, seed=it)
         if dist == "lowbits": k64 &= np.uint64(0xffffff)
@@ -96,4 +111,5 @@ while time.time() < t_end and it < args.stop_after:
         t_mark = time.time(); print("... %d sorts, %.0f M elements" % (it, elems / 1e6), flush=True)
 print("stress ok: %d sorts, %.1f M elements, %.0f s, no mismatch, no look-back fault, %d LDS-order self-tests beside running sorts: 0 mismatches"
       % (it, elems / 1e6, args.seconds, selftests))
+print("safety net of the large sort: ran %d times, %d of them sorted by counting" % (d.getParam("stat.net_runs"), d.getParam("stat.net_counting")))
 p.close(); DeviceUtils.deallocate(d); DeviceUtils.deallocate(d2)
