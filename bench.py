@@ -479,6 +479,37 @@ def main():
                     others[label] = entry
                 except Exception as e:   # never lose the metric over an extra
                     others[label] = {"error": repr(e)[:300]}
+        # config #3 once more with "sort.rank" = 0: ballot ranking everywhere, no reliance on the lane order of colliding returning DS
+        # atomics (the hardware behaviour the default ranking rests on) -- what that guarantee costs
+        if n == N_KEYS and not args.no_other_configs and "error" not in others.get("config3_key_value_64Mi_pairs", {"error": 1}):
+            try:
+                nn = 1 << 26
+                d.setParam("sort.rank", 0)
+                bb = [Buffer(d, nn, np.uint64) for _ in range(4)]
+                for i, b in enumerate(bb):
+                    b.generate(nn, seed=970 + i, kind=1)
+                p.radixSort(d, bb[0], nn)
+                DeviceUtils.waitForCompletion(d)
+                s4 = Stopwatch(d)
+                s4.start()
+                for b in bb[1:]:
+                    p.radixSort(d, b, nn)
+                s4.stop()
+                ms = s4.getMs() / 3
+                got = bb[1].toHost()
+                kk = got & np.uint64(0xffffffff)
+                vv = got >> np.uint64(32)
+                same = kk[1:] == kk[:-1]
+                ok = bool(np.all(kk[1:] >= kk[:-1])) and bool(np.all(vv[1:][same] > vv[:-1][same]))
+                others["config3_rank0_ballot_ranking"] = {"value": nn / ms / 1e6, "unit": "Gpairs/s", "ms_per_sort": ms, "elements": nn,
+                                                          "sorted_and_stable": ok}
+                del got, kk, vv, same
+                for b in bb:
+                    b.release()
+            except Exception as e:
+                others["config3_rank0_ballot_ranking"] = {"error": repr(e)[:300]}
+            finally:
+                d.setParam("sort.rank", d.getParam("sort.lds_ordered"))
         out["other_configs"] = others
         # The same sort on keys that are NOT uniform (beside the metric, not part of it): the large sort's slabs give every bucket the
         # same room, so such keys end in its safety net (counting sort for few distinct values, LSD passes otherwise) -- the bench must

@@ -54,7 +54,7 @@ enum DeviceType {
 };
 
 struct Device;
-struct SyncObject;   // events are not used by sort/scan/test; kept as an opaque name
+struct SyncObject;   // an event of the device's queue (AdlKernel.h:45-54); defined below Device
 
 struct BufferBase {
     enum BufferType {
@@ -80,8 +80,8 @@ public:
     static inline Device* allocate(DeviceType type, Config cfg = Config());
     static inline void deallocate(Device* device);
     static inline void waitForCompletion(const Device* device);
-    static inline void waitForCompletion(const SyncObject*) {}
-    static inline bool isComplete(const SyncObject*) { return true; }
+    static inline void waitForCompletion(const SyncObject* syncObj);   // AdlCL.inl:572-587
+    static inline bool isComplete(const SyncObject* syncObj);         // AdlCL.inl:589-612
     static inline void flush(const Device* device);
 };
 
@@ -123,6 +123,12 @@ struct Device {
     virtual void fillPattern(void* p, const void* pattern, int patternBytes, u64 count) const = 0;   // 4, 8 or 16 bytes
     virtual void* mapBytes(void* p, u64 bytes) const = 0;
     virtual void unmapBytes(void* p, void* host, u64 bytes) const = 0;
+    // events behind SyncObject (AdlCL.inl:98-118, 572-612): TYPE_HOST copies are synchronous, its events are always complete
+    virtual void* allocSyncObj() const { return 0; }
+    virtual void freeSyncObj(void*) const {}
+    virtual void recordSyncObj(void*) const {}
+    virtual void waitSyncObj(void*) const {}
+    virtual bool isSyncObjComplete(void*) const { return true; }
     // the C-ABI handle behind a TYPE_CL device (0 for TYPE_HOST): what Pprims hands to adlhip_*
     virtual adlhip_device* hip() const { return 0; }
 
@@ -212,6 +218,21 @@ struct DeviceHip : public Device {
         return h;
     }
     void unmapBytes(void* p, void* host, u64 bytes) const { ADLHIP_CALL(adlhip_unmap(m_hip, p, host, (size_t)bytes)); }
+    void* allocSyncObj() const
+    {
+        adlhip_event* e = 0;
+        ADLHIP_CALL(adlhip_event_create(m_hip, &e));
+        return e;
+    }
+    void freeSyncObj(void* e) const { if (e) ADLHIP_CALL(adlhip_event_destroy(m_hip, (adlhip_event*)e)); }
+    void recordSyncObj(void* e) const { if (e) ADLHIP_CALL(adlhip_event_record(m_hip, (adlhip_event*)e)); }
+    void waitSyncObj(void* e) const { if (e) ADLHIP_CALL(adlhip_event_synchronize(m_hip, (adlhip_event*)e)); }
+    bool isSyncObjComplete(void* e) const
+    {
+        int done = 1;
+        if (e) ADLHIP_CALL(adlhip_event_query(m_hip, (adlhip_event*)e, &done));
+        return done != 0;
+    }
     adlhip_device* hip() const { return m_hip; }
 
     adlhip_device* m_hip;
@@ -288,6 +309,22 @@ void DeviceUtils::deallocate(Device* device)
 void DeviceUtils::waitForCompletion(const Device* device) { device->waitForCompletion(); }
 void DeviceUtils::flush(const Device* device) { device->flush(); }
 
+// SyncObject (AdlKernel.h:45-54, AdlKernel.inl:228-239): an event of the device's queue.  A copy that is handed one records it
+// behind itself; waitForCompletion(syncObj) waits for that point of the queue only, isComplete(syncObj) polls it.  (The reference
+// also hands one to Launcher::launch1D/2D; the Launcher is out of scope here -- kernels are launched by the back-end.)
+struct SyncObject {
+    explicit SyncObject(const Device* device) : m_device(device), m_ptr(device->allocSyncObj()) {}
+    ~SyncObject() { m_device->freeSyncObj(m_ptr); }
+    const Device* m_device;
+    void* m_ptr;
+
+private:
+    SyncObject(const SyncObject&);
+    SyncObject& operator=(const SyncObject&);
+};
+void DeviceUtils::waitForCompletion(const SyncObject* syncObj) { if (syncObj) syncObj->m_device->waitSyncObj(syncObj->m_ptr); }
+bool DeviceUtils::isComplete(const SyncObject* syncObj) { return syncObj ? syncObj->m_device->isSyncObjComplete(syncObj->m_ptr) : true; }
+
 // ---------------------------------------------------------------------------------------------
 // Buffer<T>
 // ---------------------------------------------------------------------------------------------
@@ -327,24 +364,29 @@ struct Buffer : public BufferBase {
         }
     }
     // asynchronous, queue-ordered copies (Adl.inl:273-303); the caller synchronises
-    void write(const T* hostSrcPtr, u64 nElems, u64 dstOffsetNElems = 0, SyncObject* = 0)
+    // (a SyncObject, when given, is recorded behind the copy: AdlCL.inl:441-510 pass it to clEnqueue*Buffer as the event)
+    void write(const T* hostSrcPtr, u64 nElems, u64 dstOffsetNElems = 0, SyncObject* syncObj = 0)
     {
         ADLASSERT(nElems + dstOffsetNElems <= m_size);
         m_device->copyH2D(m_ptr + dstOffsetNElems, hostSrcPtr, nElems * sizeof(T));
+        if (syncObj) m_device->recordSyncObj(syncObj->m_ptr);
     }
-    void read(T* hostDstPtr, u64 nElems, u64 srcOffsetNElems = 0, SyncObject* = 0) const
+    void read(T* hostDstPtr, u64 nElems, u64 srcOffsetNElems = 0, SyncObject* syncObj = 0) const
     {
         ADLASSERT(nElems + srcOffsetNElems <= m_size);
         m_device->copyD2H(hostDstPtr, m_ptr + srcOffsetNElems, nElems * sizeof(T));
+        if (syncObj) m_device->recordSyncObj(syncObj->m_ptr);
     }
-    void write(const Buffer<T>& src, u64 nElems, SyncObject* = 0)
+    void write(const Buffer<T>& src, u64 nElems, SyncObject* syncObj = 0)
     {
         ADLASSERT(nElems <= m_size && nElems <= src.m_size);
         m_device->copyD2D(m_ptr, src.m_ptr, nElems * sizeof(T));
+        if (syncObj) m_device->recordSyncObj(syncObj->m_ptr);
     }
-    void read(Buffer<T>& dst, u64 nElems, u64 offsetNElems = 0, SyncObject* = 0) const
+    void read(Buffer<T>& dst, u64 nElems, u64 offsetNElems = 0, SyncObject* syncObj = 0) const
     {
         m_device->copyD2D(dst.m_ptr, m_ptr + offsetNElems, nElems * sizeof(T));
+        if (syncObj) m_device->recordSyncObj(syncObj->m_ptr);
     }
     void clear() { m_device->clearBytes(m_ptr, m_size * sizeof(T)); }
     void fill(void* pattern, int patternSize)
@@ -399,6 +441,91 @@ struct HostBuffer : public Buffer<T> {
     T& operator[](int idx) { return Buffer<T>::m_ptr[idx]; }
     const T& operator[](int idx) const { return Buffer<T>::m_ptr[idx]; }
     T* begin() { return Buffer<T>::m_ptr; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// BufferUtils (Adl/Adl.h:224-248, Adl.inl:370-535): a buffer of one device type seen from a device of another.
+//   map<TYPE, COPY>(device, in)       in already lives on a TYPE device -> `in` itself; TYPE_HOST -> a view of in's mapping
+//                                     (getHostPtr); else a new buffer on `device`, filled from `in` when COPY
+//   unmap<COPY>(native, orig)         the inverse: returnHostPtr / copy back when COPY, then `native` is deleted
+//   mapInplace / unmapInplace         the same into / out of a buffer the caller has allocated (nothing is deleted)
+// Copies between two device buffers go through a host bounce buffer, as the reference's do; every step is completed
+// (waitForCompletion) where the reference completes it.
+// ---------------------------------------------------------------------------------------------
+class BufferUtils {
+public:
+    template <DeviceType TYPE, bool COPY, typename T>
+    static Buffer<T>* map(const Device* device, const Buffer<T>* in, int copySize = -1)
+    {
+        ADLASSERT(device->m_type == TYPE);
+        if (in->getType() == TYPE) return const_cast<Buffer<T>*>(in);
+        ADLASSERT(copySize <= (int)in->getSize());
+        const u64 n = copySize == -1 ? in->getSize() : (u64)copySize;
+        Buffer<T>* native;
+        if (TYPE == TYPE_HOST) {   // a host view of the device buffer's mapping (valid after waitForCompletion(in's device))
+            native = new Buffer<T>;
+            native->setRawPtr(device, in->getHostPtr(n), n);
+        } else {
+            native = new Buffer<T>(device, n);
+            if (COPY) copyAcross(native, in, n);
+        }
+        return native;
+    }
+    template <bool COPY, typename T>
+    static void unmap(Buffer<T>* native, const Buffer<T>* orig, int copySize = -1)
+    {
+        if (native == orig) return;
+        if (native->getType() == TYPE_HOST) {
+            orig->returnHostPtr(native->m_ptr);
+        } else {
+            if (COPY) {
+                const u64 n = copySize == -1 ? (orig->getSize() < native->getSize() ? orig->getSize() : native->getSize()) : (u64)copySize;
+                ADLASSERT(n <= orig->getSize());
+                copyAcross(const_cast<Buffer<T>*>(orig), native, n);
+            }
+            DeviceUtils::waitForCompletion(native->m_device);
+        }
+        delete native;
+    }
+    template <DeviceType TYPE, bool COPY, typename T>
+    static Buffer<T>* mapInplace(const Device* device, Buffer<T>* allocatedBuffer, const Buffer<T>* in, int copySize = -1)
+    {
+        ADLASSERT(device->m_type == TYPE);
+        if (in->getType() == TYPE) return const_cast<Buffer<T>*>(in);
+        ADLASSERT(copySize <= (int)in->getSize());
+        const u64 n = copySize == -1 ? (in->getSize() < allocatedBuffer->getSize() ? in->getSize() : allocatedBuffer->getSize()) : (u64)copySize;
+        if (COPY) copyAcross(allocatedBuffer, in, n);
+        return allocatedBuffer;
+    }
+    template <bool COPY, typename T>
+    static void unmapInplace(Buffer<T>* native, const Buffer<T>* orig, int copySize = -1)
+    {
+        if (native == orig || !COPY) return;
+        const u64 n = copySize == -1 ? (orig->getSize() < native->getSize() ? orig->getSize() : native->getSize()) : (u64)copySize;
+        ADLASSERT(n <= orig->getSize());
+        copyAcross(const_cast<Buffer<T>*>(orig), native, n);
+    }
+
+private:
+    // dst[0, n) = src[0, n) across device types, completed on return (Adl.inl:392-410, 436-452)
+    template <typename T>
+    static void copyAcross(Buffer<T>* dst, const Buffer<T>* src, u64 n)
+    {
+        if (src->getType() == TYPE_HOST) {
+            dst->write(src->m_ptr, n);
+            DeviceUtils::waitForCompletion(dst->m_device);
+        } else if (dst->getType() == TYPE_HOST) {
+            src->read(dst->m_ptr, n);
+            DeviceUtils::waitForCompletion(src->m_device);
+        } else {
+            T* tmp = new T[n];
+            src->read(tmp, n);
+            DeviceUtils::waitForCompletion(src->m_device);
+            dst->write(tmp, n);
+            DeviceUtils::waitForCompletion(dst->m_device);
+            delete[] tmp;
+        }
+    }
 };
 
 // ---------------------------------------------------------------------------------------------

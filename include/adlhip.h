@@ -133,8 +133,8 @@ int adlhip_unmap(adlhip_device* dev, void* dptr, void* hptr, size_t bytes);
  *   *tmp_bytes  : second data buffer, n elements
  *   *work_bytes : control scratch (digit tables / tile status words) and, for the sizes the large sort takes
  *                 ("sort.msd2": sorts of more than 1 Mi elements), its bucket and segment slabs -- about 1.5 x n elements
- *                 for whole u32 keys from 16 Mi keys up (their 16-bit second slab then lives in d_tmp; 64 Mi keys: 0.41 GB),
- *                 3 x n elements otherwise (64 Mi pairs: 1.7 GB; 256 Mi u64 keys: 6.6 GB).  The value
+ *                 for whole u32 keys from 16 Mi keys up (their 16-bit second slab then lives in d_tmp; 64 Mi keys: 451 MB),
+ *                 3 x n elements otherwise (64 Mi pairs: 1.7 GB; 256 Mi u64 keys: 6.1 GB).  The value
  *                 suffices for EVERY n' <= n with the current knobs (the need of a single n is not monotone:
  *                 smaller inputs use smaller tiles and so more status rows), so a caller may size its scratch
  *                 once for its largest batch; changing "sort.tile", "sort.digit_bits" or "sort.algo" later can
@@ -145,14 +145,15 @@ int adlhip_radix_sort_scratch_bytes(adlhip_device* dev, int elem_kind, size_t n,
 /* The same for a sort on `sort_bits` bits, at one of three levels (sizes: level 0 <= level 2 <= level 1):
  *   level 0: the minimum -- the reference's own contract (Pprims.cpp:332-337: the n-element partner array and a digit table of
  *            a few KiB).  Every sort entry point accepts a work buffer of this size; the sort then runs the per-digit
- *            three-kernel passes (64 Mi u32 keys: 75 instead of 164 Gkeys/s).
+ *            three-kernel passes (64 Mi u32 keys: 75-81 instead of 206-215 Gkeys/s, profiles/r4_bench_n1.json).
  *   level 1: full speed -- what adlhip_radix_sort_scratch_bytes reports for whole keys.  A sort on fewer bits than the key has
  *            takes the stable form of the large sort, whose second slab cannot shrink to 16 bits per key, and so needs more.
  *   level 2: lean -- whole u32 / u64 keys keep the large sort (cursor form) with 12 % instead of 50 % of head-room in the
- *            first pass's bucket slabs: 64 Mi u32 keys 307 MB of work instead of 451, same speed on keys spread evenly over
+ *            first pass's bucket slabs: 64 Mi u32 keys 306 MB of work instead of 451, same speed on keys spread evenly over
  *            their range; keys whose density varies by more than ~10 % from one 256th of the range to the next go through
- *            the safety net once and then, by the handle's hints, to the one-sweep passes.  Pairs, SoA and sorts on part of
- *            the key get the one-sweep passes' size (their slabs cannot shrink this way).
+ *            the safety net inside the sort (correct, about 4 x slower; nothing is remembered between sorts).  Pairs, SoA and sorts
+ *            on part of the key keep the stable form of the large sort with statistical head-room only (mean + 8 sd in the first
+ *            pass's sub-slabs, + 7.5 sd in the segment slabs, instead of + 50 %): 64 Mi pairs 1.25 GB instead of 1.7.
  * With a work buffer between the levels, every path checks its own need and the sort takes the fastest one that fits. */
 int adlhip_radix_sort_scratch_bytes_for(adlhip_device* dev, int elem_kind, size_t n, int sort_bits, int level,
                                         size_t* tmp_bytes, size_t* work_bytes);
@@ -292,7 +293,7 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
 /* Integer tunables, by name.  Unknown names fail.  Current names:
  *   "sort.algo"        -1 [default] = by size: n <= 16384 one workgroup does the whole sort in one launch;
  *                      n <= 2 Mi the mid-size sort ("sort.mid"), above it the large sort ("sort.msd2"); for what
- *                      those do not take (partial sort_bits, SoA, keys their hints have sent back): below
+ *                      those do not take (sort_bits < 16, a work buffer below level 1, sizes beyond their limits): below
  *                      24 MiB of data the three-kernel pass, from there on the one-sweep path
  *                      0 = onesweep (one sweep per digit, 16 decoupled look-back chains)
  *                      1 = three kernels per pass: count -> table scan -> sort+scatter (the
@@ -307,8 +308,10 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      instruction that hit the same address are served in ascending lane order); it is
  *                      checked at device creation and can be re-checked at any time
  *                      (adlhip_selftest_lds_order).  Mode 0 is the safe fallback: documented wave
- *                      intrinsics only, ~1.6x the pass time.  Every LSD pass must be stable, so key-only
- *                      sorts depend on this as much as key-value sorts do.
+ *                      intrinsics only.  Pairs (AoS and SoA) keep the stable large sort in mode 0 -- its passes, its
+ *                      wave-per-segment finish and its safety net have ballot-ranked variants (up to 96 Mi pairs) --; keys
+ *                      take the per-digit passes (~1.4 x the time).  Every LSD pass must be stable, so key-only
+ *                      sorts depend on the ranking as much as key-value sorts do.
  *   "sort.lds_ordered" (read-only) result of that self-test
  *   "sort.mid"         1 [default] / 0: between 8 Ki and 2 Mi u32 keys (16 Ki and 1 Mi pairs), full 32-bit sorts take two
  *                      launches (u32 keys: MSD pass with bucket cursors, buckets finished in LDS) or three
@@ -360,6 +363,11 @@ int adlhip_event_create(adlhip_device* dev, adlhip_event** out);
 int adlhip_event_record(adlhip_device* dev, adlhip_event* ev);
 int adlhip_event_elapsed_ms(adlhip_device* dev, adlhip_event* start, adlhip_event* stop, float* ms);
 int adlhip_event_destroy(adlhip_device* dev, adlhip_event* ev);
+/* DeviceCL::waitForCompletion(const SyncObject*) / isComplete(const SyncObject*) -- Adl/CL/AdlCL.inl:572-612 (clWaitForEvents /
+ * clGetEventInfo on the event a copy or launch was given): wait for / poll the point of the stream at which `ev` was last
+ * recorded.  An event that was never recorded counts as complete. */
+int adlhip_event_synchronize(adlhip_device* dev, adlhip_event* ev);
+int adlhip_event_query(adlhip_device* dev, adlhip_event* ev, int* done_out);
 
 /* Per-kernel launch timing collected while "profile" = 1 (replaces the per-launch CSV rows of
  * Adl/CL/AdlKernelUtilsCL.inl:664-677).  adlhip_profile_count synchronises the stream and folds the

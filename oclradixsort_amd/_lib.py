@@ -85,6 +85,8 @@ SIGNATURES = {
     "adlhip_event_record": (_I, [_VP, _VP]),
     "adlhip_event_elapsed_ms": (_I, [_VP, _VP, _VP, ctypes.POINTER(ctypes.c_float)]),
     "adlhip_event_destroy": (_I, [_VP, _VP]),
+    "adlhip_event_synchronize": (_I, [_VP, _VP]),
+    "adlhip_event_query": (_I, [_VP, _VP, ctypes.POINTER(_I)]),
     "adlhip_profile_reset": (_I, [_VP]),
     "adlhip_profile_count": (_I, [_VP]),
     "adlhip_profile_get": (_I, [_VP, _I, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64),

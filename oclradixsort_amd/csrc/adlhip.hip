@@ -704,7 +704,7 @@ int launch_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* s
     });
 }
 
-template <typename E, int K, typename S = E, bool SOA = false>
+template <typename E, int K, typename S = E, bool SOA = false, int RANK = 1>
 int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32_t* seg_start, size_t num_segments, int low_bits,
                              const uint32_t* seg_cnt = nullptr, uint32_t in_stride = 0, const uint32_t* gate = nullptr,
                              const uint32_t* dyn_low_bits = nullptr, uint32_t* out_vals = nullptr, const uint32_t* list = nullptr,
@@ -731,7 +731,7 @@ int launch_wave_segment_sort(adlhip_device* d, const E* in, E* out, const uint32
             return fail("internal: no list form for SoA");
         }
     }
-    auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES, STEP, RMIN, S, SOA, false>;
+    auto kern = adlhip::wave_segment_sort_kernel<E, K, WAVES, STEP, RMIN, S, SOA, false, RANK>;
     if (ensure_lds(kern, lds)) return ADLHIP_FAILURE;
     const uint32_t grid = (uint32_t)((num_segments + WAVES - 1) / WAVES);
     return launch(d, sizeof(E) == 4 ? "segment_sort_wave_u32" : "segment_sort_wave_e64", [&] {
@@ -1010,12 +1010,13 @@ uint32_t msd2_tier_b(size_t n, uint32_t slots = 65536, bool fine = false)
 }
 // elements between two segment slabs: the mean + 50 % (or + 7.5 sd where that is more), at most the finish's tile.  (Round 2 spaced
 // the slabs by the tile whatever n was: 168 MB of second slab for 2 Mi keys.)
-uint32_t msd2_stride_b(size_t n, uint32_t slots = 65536, bool fine = false)
+uint32_t msd2_stride_b(size_t n, uint32_t slots = 65536, bool fine = false, bool lean = false)
 {
     const size_t mean = (n + slots - 1) / slots;
     size_t sd = 1;
     while (sd * sd < mean) ++sd;
-    const size_t want = align_up(std::max(mean + mean / 2, mean + (15 * sd + 1) / 2) + 8, 64);
+    // lean (level 2 of adlhip_radix_sort_scratch_bytes_for, stable form): the mean + 7.5 sd only -- what evenly spread keys need
+    const size_t want = align_up(std::max(lean ? mean : mean + mean / 2, mean + (15 * sd + 1) / 2) + 8, 64);
     return (uint32_t)std::min<size_t>(want, msd2_tier_b(n, slots, fine));
 }
 
@@ -1202,7 +1203,10 @@ struct Msd2sLayout {
 
 // slab16: whole u32 keys -- the second slab holds their low 16 bits and, from 16 Mi keys, sits in the caller's n-element scratch
 // array (see Msd2Layout::slab_b_in_tmp)
-Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8, bool slab16 = false)
+// lean: the sub-slabs of the first pass and the segment slabs keep statistical head-room only (mean + 8 sd / + 7.5 sd instead of
+// + 50 %): 64 Mi pairs 1.25 GB of work instead of 1.7.  Evenly spread keys run at the same speed; keys whose density varies by more
+// than a few per cent between neighbouring parts of their range take the safety net.
+Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8, bool slab16 = false, bool lean = false)
 {
     Msd2sLayout L;
     const uint32_t kMsd2sTile = msd2s_tile(elem_bytes);
@@ -1217,7 +1221,7 @@ Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8, bool slab16 = false)
         const size_t mean = slice / 256;
         size_t sd = 1;
         while (sd * sd < mean) ++sd;
-        const size_t stride = align_up(mean + mean / 2 + 8 * sd + 64, 64);   // + 50 %: as much skew as the segment slabs take
+        const size_t stride = align_up(mean + (lean ? 0 : mean / 2) + 8 * sd + 64, 64);   // + 50 %: as much skew as the segment slabs take
         const double waste = (double)((stride + kMsd2sTile - 1) / kMsd2sTile) * kMsd2sTile / (double)mean;
         if (waste < best - 1e-9) {
             best = waste;
@@ -1232,7 +1236,7 @@ Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8, bool slab16 = false)
     // (whole u32 keys keep 65536 segments: their second slab holds 16-bit keys only while the finish has 16 bits to sort)
     L.seg_shift = slab16 ? 8u : msd2_seg_shift(n, false);
     L.slots = 256u << L.seg_shift;
-    L.stride_b = msd2_stride_b(n, L.slots, slab16);
+    L.stride_b = msd2_stride_b(n, L.slots, slab16, lean);
     L.tier_b = msd2_tier_b(n, L.slots, slab16);
     L.ticket_words = (32 + 256) * adlhip::kTicketStride;
     L.status_bytes_a = (size_t)L.pieces * L.rows_a * 1024;
@@ -1249,7 +1253,7 @@ Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8, bool slab16 = false)
     // rows of pass A <= n/tile + 16, rows of a bucket in pass B <= its sub-slabs / tile + 16
     size_t sdb = 1;
     while (sdb * sdb * 4096 < n) ++sdb;   // >= sd of every choice (a sub-slab's mean is at most n / 4096 + 32)
-    const size_t bucket_bound = n / 256 + n / 512 + 24 * (32 + 16 + 8 * (sdb + 1) + 128);
+    const size_t bucket_bound = n / 256 + (lean ? 0 : n / 512) + 24 * (32 + 16 + 8 * (sdb + 1) + 128);
     const size_t rows_a_bound = n / kMsd2sTile + 24;
     const size_t rows_b_bound = bucket_bound / kMsd2sTile + 25;
     L.off_status_a = align_up(L.off_tickets + (size_t)L.ticket_words * 4, 256);
@@ -1273,11 +1277,14 @@ Msd2sLayout msd2s_layout(size_t n, size_t elem_bytes = 8, bool slab16 = false)
 enum LargeForm { kLargeNone = 0, kLargeCursor, kLargeStable, kLargeHybrid };
 LargeForm large_sort_form(const adlhip_device* d, size_t elem_bytes, bool keys, size_t n, int sort_bits, int max_bits)
 {
-    if (!(d->sort_algo < 0 && d->msd2_path && d->rank_mode == 1 && d->digit_bits == 8 && d->tile_variant < 0)) return kLargeNone;
+    if (!(d->sort_algo < 0 && d->msd2_path && d->digit_bits == 8 && d->tile_variant < 0)) return kLargeNone;
     if (d->resident_wgs < 256) return kLargeNone;   // the safety net's grid barrier spans 256 workgroups
     if (sort_bits < 16) return kLargeNone;          // two 8-bit digits must fit inside the sorted bits
     const bool forced = d->msd2_path >= 2;
     const bool whole = sort_bits == max_bits;
+    // "sort.rank" = 0 (no reliance on the lane order of colliding DS atomics): pairs keep the stable form -- its passes and its
+    // wave-per-segment finish have ballot-ranked variants (tiles up to 2560 pairs: n <= 96 Mi) --, keys take the per-digit passes
+    if (d->rank_mode != 1 && (keys || n > (size_t(96) << 20) || msd2_tier_b(n, 256u << msd2_seg_shift(n, false)) > 2560u)) return kLargeNone;
     if (!keys) return n > (forced ? kMsd2Min : kMsd2sAutoMin) && n <= kMsd2sMax ? kLargeStable : kLargeNone;
     // u64 keys have no mid-size sort (it serves 32-bit keys), and with the narrow second digit and the binning finish the large sort
     // beats their per-digit passes from the one-workgroup sort's limit up: 100 K keys 78 -> 32 us, 1 Mi 117 -> 47, 2 Mi 172 -> 52
@@ -1373,6 +1380,14 @@ int launch_large_finish(adlhip_device* d, const E* slab_b, E* out, uint32_t* out
             return launch_wave_segment_sort<E, 80, S>(d, slab_b, out, seg_off, slots, low_bits_max, seg_cnt, stride_b, mode, lowb, nullptr, hard, hc, seg_shift);
         }
     }
+    if constexpr (sizeof(E) == 8 && sizeof(S) == 8) {
+        if (d->rank_mode == 0) {   // "sort.rank" = 0 (pairs; large_sort_form keeps n within these tiles): the ballot-ranked finish
+            if (tier_b == 1280) return launch_wave_segment_sort<E, 20, S, SOA, 0>(d, slab_b, out, seg_off, slots, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals, nullptr, nullptr, seg_shift);
+            if (tier_b == kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S, SOA, 0>(d, slab_b, out, seg_off, slots, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals, nullptr, nullptr, seg_shift);
+            if (tier_b == 2560) return launch_wave_segment_sort<E, 40, S, SOA, 0>(d, slab_b, out, seg_off, slots, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals, nullptr, nullptr, seg_shift);
+            return fail("internal: no ballot-ranked finish for segments of %u elements", tier_b);
+        }
+    }
     if (tier_b == 1280) return launch_wave_segment_sort<E, 20, S, SOA>(d, slab_b, out, seg_off, slots, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals, nullptr, nullptr, seg_shift);
     if (tier_b == kMsd2Stride0) return launch_wave_segment_sort<E, kMsd2Stride0 / 64, S, SOA>(d, slab_b, out, seg_off, slots, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals, nullptr, nullptr, seg_shift);
     if (tier_b == 2560) return launch_wave_segment_sort<E, 40, S, SOA>(d, slab_b, out, seg_off, slots, low_bits_max, seg_cnt, stride_b, mode, lowb, out_vals, nullptr, nullptr, seg_shift);
@@ -1401,7 +1416,7 @@ bool use_bin_finish(const adlhip_device* d, size_t elem_bytes, bool key64, size_
 // 0.172 by look-back (profiles/r3_first_ab_cursor_vs_lookback_u32.txt).
 template <typename E, bool KEY64>
 int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort_bits, uint32_t* soa_keys = nullptr,
-               uint32_t* soa_vals = nullptr, bool hybrid = false)
+               uint32_t* soa_vals = nullptr, bool hybrid = false, bool lean = false)
 {
     constexpr int K = sizeof(E) == 8 ? 16 : 32;
     constexpr bool k32 = sizeof(E) == 4;
@@ -1410,7 +1425,7 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
     uint32_t* flag = d->d_msd2 + 8192 + 65536;
     uint32_t* done = flag + 1;
     uint32_t* bar = flag + 2;
-    const Msd2sLayout L = msd2s_layout(n, sizeof(E), k32 && whole);
+    const Msd2sLayout L = msd2s_layout(n, sizeof(E), k32 && whole, lean);
     if (L.total == 0) return fail("internal: layout bounds of the stable large sort");
     char* wb = reinterpret_cast<char*>(work);
     uint32_t* mode = reinterpret_cast<uint32_t*>(wb + L.off_mode);
@@ -1426,6 +1441,9 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
     using CT = adlhip::TileCfg<E, 8, 512, K>;
     static_assert(CT::TILE == (int)msd2s_tile(sizeof(E)), "layout and kernel agree on the tile");
     auto kern = adlhip::msd_lookback_scatter_kernel<E, 512, K, KEY64>;
+    if constexpr (sizeof(E) == 8 && !KEY64) {   // pairs with "sort.rank" = 0: ballot ranking in the passes (and in the finish, below)
+        if (d->rank_mode == 0) kern = adlhip::msd_lookback_scatter_kernel<E, 512, K, KEY64, 0>;
+    }
     if (ensure_lds(kern, CT::LDS_BYTES)) return ADLHIP_FAILURE;
     // status rows of both passes: zero (one memset; the rows are contiguous).  Hybrid: pass A's only.
     HIPCHK(hipMemsetAsync(status_a, 0, hybrid ? L.status_bytes_a : (L.off_status_b - L.off_status_a) + L.status_bytes_b, d->stream));
@@ -1488,6 +1506,9 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
     adlhip::DictBlock* net_dict = (k32 || KEY64) && whole && !soa_keys && d->dict_path ? d->d_dict : nullptr;
     using CC = adlhip::TileCfg<E, 8, 512, NK>;   // the safety net's tile (it runs in the offsets kernel when a run did not fit)
     auto ko = adlhip::msd2s_offsets_kernel<E, CT::TILE, 512, NK>;
+    if constexpr (sizeof(E) == 8 && !KEY64) {
+        if (d->rank_mode == 0) ko = adlhip::msd2s_offsets_kernel<E, CT::TILE, 512, NK, 0>;   // the net ranks by ballots too
+    }
     if (ensure_lds(ko, CC::LDS_BYTES)) return ADLHIP_FAILURE;
     rc = launch(d, "msd2s_offsets", [&] {
         hipLaunchKernelGGL(ko, dim3(net_wgs(d)), dim3(512), CC::LDS_BYTES, d->stream,
@@ -1540,8 +1561,9 @@ size_t sort_work_bytes_at(const adlhip_device* d, int elem_kind, size_t n, int s
     const bool whole = sort_bits == max_bits;
     const bool keys = elem_kind == ADLHIP_ELEM_U32 || elem_kind == ADLHIP_ELEM_U64;
     if (n > kMsd2Min && sort_bits >= 16) {
-        if (level == 2) {   // lean: whole keys keep the cursor form with little head-room; every other sort runs the one-sweep passes
+        if (level == 2) {   // lean: whole keys keep the cursor form with little head-room, pairs and partial sorts the stable form
             if (keys && whole && n <= (eb == 4 ? kMsd2MaxU32 : kMsd2MaxU64)) e = msd2_layout(n, eb, kLeanHeadroomPct).total;
+            else if (n <= kMsd2sMax) e = msd2s_layout(n, eb, false, true).total;
         } else {
             if (n <= kMsd2sMax) e = msd2s_layout(n, eb, eb == 4 && whole).total;
             if (keys && whole && n <= (eb == 4 ? kMsd2MaxU32 : kMsd2MaxU64)) e = std::max(e, msd2_layout(n, eb).total);
@@ -1635,6 +1657,7 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
     const bool keys = (int)sizeof(E) * 8 == max_bits;
     LargeForm form = large_sort_form(d, sizeof(E), keys, n, sort_bits, max_bits);
     int headroom = kFullHeadroomPct;
+    bool lean_stable = false;
     if (form != kLargeNone && large_work_bytes(form, sizeof(E), n, sort_bits == max_bits) > work_bytes) {
         // the slabs do not fit the caller's work buffer: whole keys may still fit the cursor form (its second slab is smaller),
         // at full head-room or at the lean one (level 2 of adlhip_radix_sort_scratch_bytes_for)
@@ -1645,6 +1668,9 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
         } else if (cursor_ok && msd2_layout(n, sizeof(E), kLeanHeadroomPct).total <= work_bytes) {
             form = kLargeCursor;
             headroom = kLeanHeadroomPct;
+        } else if (n <= kMsd2sMax && msd2s_layout(n, sizeof(E), false, true).total <= work_bytes) {
+            form = kLargeStable;   // pairs, partial sorts: the stable form with statistical head-room only
+            lean_stable = true;
         } else {
             form = kLargeNone;
         }
@@ -1657,10 +1683,11 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
         if (form == kLargeCursor) return msd2_sort<E>(d, data, tmp, work, n, headroom);
         const bool hybrid = form == kLargeHybrid;
         if constexpr (sizeof(E) == 4) {
-            return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits, nullptr, nullptr, hybrid);
+            // (lean: whole u32 keys would have taken the cursor form; here the keys are sorted on part of their bits)
+            return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits, nullptr, nullptr, hybrid, lean_stable);
         } else {
-            if (keys) return msd2s_sort<E, true>(d, data, tmp, work, n, sort_bits, nullptr, nullptr, hybrid);
-            return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits);
+            if (keys) return msd2s_sort<E, true>(d, data, tmp, work, n, sort_bits, nullptr, nullptr, hybrid, lean_stable);
+            return msd2s_sort<E, false>(d, data, tmp, work, n, sort_bits, nullptr, nullptr, false, lean_stable);
         }
     }
     return run_sort<AosBuf<E>>(d, AosBuf<E>{data}, AosBuf<E>{tmp}, work, work_bytes, n, plan);
@@ -2296,8 +2323,12 @@ int adlhip_radix_sort_soa32(adlhip_device* d, uint32_t* keys, uint32_t* vals, ui
     if (!vals || !tmp_vals) return fail("null value buffer passed to radix sort");
     if ((reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(tmp_vals)) & 15u)
         return fail("sort buffers must be 16-byte aligned");
-    if (large_sort_form(d, 8, false, n, sort_bits, 32) != kLargeNone && large_work_bytes(kLargeStable, 8, n, sort_bits == 32) <= work_bytes)
-        return msd2s_sort<uint64_t, false>(d, nullptr, nullptr, work, n, sort_bits, keys, vals);
+    if (large_sort_form(d, 8, false, n, sort_bits, 32) != kLargeNone) {
+        if (large_work_bytes(kLargeStable, 8, n, sort_bits == 32) <= work_bytes)
+            return msd2s_sort<uint64_t, false>(d, nullptr, nullptr, work, n, sort_bits, keys, vals);
+        if (msd2s_layout(n, 8, false, true).total <= work_bytes)   // level 2, lean
+            return msd2s_sort<uint64_t, false>(d, nullptr, nullptr, work, n, sort_bits, keys, vals, false, true);
+    }
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
     return run_sort<SoaBuf>(d, SoaBuf{keys, vals}, SoaBuf{tmp_keys, tmp_vals}, work, work_bytes, n, plan);
 }
@@ -2566,6 +2597,25 @@ int adlhip_event_elapsed_ms(adlhip_device* d, adlhip_event* a, adlhip_event* b, 
     if (!a || !b || !ms) return fail("null argument");
     HIPCHK(hipEventSynchronize(b->ev));
     HIPCHK(hipEventElapsedTime(ms, a->ev, b->ev));
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_event_synchronize(adlhip_device* d, adlhip_event* ev)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!ev) return fail("null event");
+    HIPCHK(hipEventSynchronize(ev->ev));   // (an event that was never recorded is complete)
+    return ADLHIP_SUCCESS;
+}
+
+int adlhip_event_query(adlhip_device* d, adlhip_event* ev, int* done)
+{
+    if (bind(d)) return ADLHIP_FAILURE;
+    if (!ev || !done) return fail("null argument");
+    const hipError_t e = hipEventQuery(ev->ev);
+    if (e != hipSuccess && e != hipErrorNotReady) return fail("hipEventQuery failed: %s", hipGetErrorString(e));
+    (void)hipGetLastError();   // hipErrorNotReady is an answer, not an error to leave behind
+    *done = e == hipSuccess ? 1 : 0;
     return ADLHIP_SUCCESS;
 }
 

@@ -127,7 +127,7 @@ __device__ __forceinline__ void coop_count_range(const E* __restrict__ src, uint
     for (uint32_t s = e0 + nvec * VEC + (uint32_t)tid; s < e1; s += NT) atomicAdd(&my_hist[dig(src[s])], 1u);
 }
 
-template <typename E, int NT, int K>
+template <typename E, int NT, int K, int RANK = 1>
 __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table, uint32_t* __restrict__ totals,
                                               uint32_t* bar, uint32_t* fault, unsigned char* smem, int key_bits = 32,
                                               uint32_t target0 = 0u /* what the barrier counter has reached on entry */,
@@ -195,10 +195,10 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
                 const uint32_t left = n - tb;
                 const uint32_t valid = left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE;
                 if (narrow)
-                    sort_scatter_tile<AosIO<E>, 4, NT, K, 1>(io, tb, valid, n, sb, smem,
+                    sort_scatter_tile<AosIO<E>, 4, NT, K, RANK>(io, tb, valid, n, sb, smem,
                                                              [&](int, uint32_t c) { const uint32_t g = carry; carry += c; return g; });
                 else
-                    sort_scatter_tile<AosIO<E>, 8, NT, K, 1>(io, tb, valid, n, sb, smem,
+                    sort_scatter_tile<AosIO<E>, 8, NT, K, RANK>(io, tb, valid, n, sb, smem,
                                                              [&](int, uint32_t c) { const uint32_t g = carry; carry += c; return g; });
             }
         }
@@ -215,7 +215,7 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
 // dict_kernels.hpp -- sample, look up and count, fill -- and only if the keys take more than 256 values, or one of them missed the
 // dictionary, the LSD passes.  `bar` is zero on entry.  No launch of its own, no word for the host to read: the same input takes the
 // same time whether it is the handle's first sort or its hundredth.
-template <typename E, int NT, int K>
+template <typename E, int NT, int K, int RANK = 1>
 __device__ __forceinline__ void net_sort(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table, uint32_t* bar, uint32_t* fault,
                                          unsigned char* smem, int key_bits, DictBlock* dict, uint32_t* stats, uint32_t target0 = 0u)
 {
@@ -237,7 +237,7 @@ __device__ __forceinline__ void net_sort(E* data, E* tmp, uint32_t n, uint32_t* 
             __syncthreads();   // (the fill's LDS is the LSD sort's)
         }
     }
-    coop_lsd_sort<E, NT, K>(data, tmp, n, table, table + 256 * wgs, bar, fault, smem, key_bits, target);
+    coop_lsd_sort<E, NT, K, RANK>(data, tmp, n, table, table + 256 * wgs, bar, fault, smem, key_bits, target);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -492,7 +492,11 @@ __global__ __launch_bounds__(NT) void segment_sort_kernel(const E* in, E* out, c
 // S = type of the stored elements: E, or uint16_t -- the large sort keeps only the low 16 bits of u32 keys in its second slab
 // (the bits above are the segment's number) and `hi` puts them back at the final store.
 // SOA: the destination is two u32 arrays (keys = dst reinterpreted, values = dst_vals), E = {key, value} as one u64.
-template <typename E, int R, int F, typename S, bool SOA>
+// RANK == 0: the slots are handed out WITHOUT relying on the lane order of colliding returning DS atomics ("sort.rank" = 0): the
+// lanes of one instruction that share a digit find each other by ballots (8 per element), take the bin's running start by a plain
+// LDS read and their place by counting the peers below them; the lowest peer moves the start on.  DS operations of one wave
+// execute in issue order, so the next row's read sees this row's store.  Documented wave intrinsics only; ~2 x the ALU work.
+template <typename E, int R, int F, typename S, bool SOA, int RANK = 1>
 __device__ __forceinline__ void wave_sort_rows(const S* __restrict__ src, E* __restrict__ dst, uint32_t* __restrict__ dst_vals, uint32_t m,
                                                int lane, E* __restrict__ buf, uint32_t* __restrict__ cnt, uint32_t low_bits, E hi)
 {
@@ -557,9 +561,29 @@ __device__ __forceinline__ void wave_sort_rows(const S* __restrict__ src, E* __r
         // slots: one returning atomic per element, then its store.  Small tiles (many waves per CU) go element by element; the
         // large tiles of the big segments (K = 40, 80: one to four waves per CU) would sit out one LDS round trip per element,
         // so they take their slots eight at a time
+        if constexpr (RANK == 0) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                if (j < F || j * 64 < rem) {
+                    const uint32_t dg = digit(e[j]);
+                    const uint64_t act = __ballot(true);   // the lanes that hold an item of this row
+                    uint64_t peers = act;
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const bool bit = (dg >> b) & 1u;
+                        const uint64_t bal = __ballot(bit);
+                        peers &= bit ? bal : ~bal;
+                    }
+                    const uint32_t below = mbcnt64(peers);
+                    const uint32_t base = __hip_atomic_load(&cnt[dg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    if (below == 0u) __hip_atomic_store(&cnt[dg], base + (uint32_t)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    buf[base + below] = e[j];
+                }
+            }
+        }
         constexpr int B = R > 20 ? 8 : 1;   // 16 for the largest tile measured the same
 #pragma unroll
-        for (int j0 = 0; j0 < R; j0 += B) {
+        for (int j0 = 0; RANK != 0 && j0 < R; j0 += B) {
             uint32_t pos[B];
 #pragma unroll
             for (int jj = 0; jj < B; ++jj) {
@@ -596,7 +620,7 @@ __device__ __forceinline__ void wave_sort_rows(const S* __restrict__ src, E* __r
 // rows -> the smallest body that holds them: bodies for RMIN (any number of rows up to RMIN: every row tested), RMIN + STEP,
 // ..., K rows.  A kernel for large tiles (K = 40, 80: segments of the large sort beyond 64 Mi keys) starts at K / 2 -- its
 // segments are that large -- and steps by 4 to keep the code size in bounds.
-template <typename E, int R, int K, int STEP, bool FIRST, typename S, bool SOA>
+template <typename E, int R, int K, int STEP, bool FIRST, typename S, bool SOA, int RANK = 1>
 __device__ __forceinline__ void wave_sort_dispatch(int rows, const S* __restrict__ src, E* __restrict__ dst, uint32_t* __restrict__ dst_vals,
                                                    uint32_t m, int lane, E* __restrict__ buf, uint32_t* __restrict__ cnt, uint32_t low_bits,
                                                    E hi)
@@ -604,10 +628,10 @@ __device__ __forceinline__ void wave_sort_dispatch(int rows, const S* __restrict
     constexpr int RR = R < K ? R : K;
     constexpr int F = FIRST ? 0 : RR - STEP;
     if constexpr (R >= K) {
-        wave_sort_rows<E, RR, F, S, SOA>(src, dst, dst_vals, m, lane, buf, cnt, low_bits, hi);
+        wave_sort_rows<E, RR, F, S, SOA, RANK>(src, dst, dst_vals, m, lane, buf, cnt, low_bits, hi);
     } else {
-        if (rows <= R) wave_sort_rows<E, RR, F, S, SOA>(src, dst, dst_vals, m, lane, buf, cnt, low_bits, hi);
-        else wave_sort_dispatch<E, R + STEP, K, STEP, false, S, SOA>(rows, src, dst, dst_vals, m, lane, buf, cnt, low_bits, hi);
+        if (rows <= R) wave_sort_rows<E, RR, F, S, SOA, RANK>(src, dst, dst_vals, m, lane, buf, cnt, low_bits, hi);
+        else wave_sort_dispatch<E, R + STEP, K, STEP, false, S, SOA, RANK>(rows, src, dst, dst_vals, m, lane, buf, cnt, low_bits, hi);
     }
 }
 
@@ -626,7 +650,7 @@ __device__ __forceinline__ uint32_t slot_to_segment(uint32_t slot, uint32_t w)
 // LIST: the segments to do are list[0 .. *list_cnt) -- what bin_segment_sort_kernel handed over, usually nothing -- taken in turns
 // by a small grid; otherwise wave i of the grid does segment i.  (One call site of the body per instantiation: with two, the
 // compiler stops inlining the 80-row bodies and the kernel runs three times slower.)
-template <typename E, int K, int WAVES, int STEP, int RMIN, typename S, bool SOA, bool LIST>
+template <typename E, int K, int WAVES, int STEP, int RMIN, typename S, bool SOA, bool LIST, int RANK = 1>
 __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* in, E* out, const uint32_t* __restrict__ seg_start,
                                                                         uint32_t num_segments, uint32_t low_bits, uint32_t* fault,
                                                                         const uint32_t* __restrict__ seg_cnt, uint32_t in_stride,
@@ -665,13 +689,13 @@ __global__ __launch_bounds__(64 * WAVES) void wave_segment_sort_kernel(const E* 
         }
         if constexpr (SOA) {
             const E* src = in + (size_t)sl * in_stride;
-            wave_sort_dispatch<E, RMIN, K, STEP, true, E, true>((int)((m + 63u) >> 6), src,
+            wave_sort_dispatch<E, RMIN, K, STEP, true, E, true, RANK>((int)((m + 63u) >> 6), src,
                                                                 reinterpret_cast<E*>(reinterpret_cast<uint32_t*>(out) + begin),
                                                                 out_vals + begin, m, lane, buf, cnt, low_bits, E(0));
         } else if constexpr (sizeof(S) == sizeof(E)) {
             const E* src = in + (seg_cnt ? (size_t)sl * in_stride : (size_t)begin);
-            wave_sort_dispatch<E, RMIN, K, STEP, true, E, false>((int)((m + 63u) >> 6), src, out + begin, nullptr, m, lane, buf, cnt,
-                                                                 low_bits, E(0));
+            wave_sort_dispatch<E, RMIN, K, STEP, true, E, false, RANK>((int)((m + 63u) >> 6), src, out + begin, nullptr, m, lane, buf, cnt,
+                                                                       low_bits, E(0));
         } else {
             // slab form with 16-bit elements: the key's bits above low_bits are (sampled prefix, segment number); seg_shift = 8
             const S* src = reinterpret_cast<const S*>(in) + (size_t)sl * in_stride;
@@ -1530,7 +1554,7 @@ struct LookbackPass {
     uint32_t seg_shift;           // pass B: width w of the second digit (slot_to_segment); 8 otherwise
 };
 
-template <typename E, int NT, int K, bool KEY64>
+template <typename E, int NT, int K, bool KEY64, int RANK = 1>
 __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E> a)
 {
     using C = TileCfg<E, 8, NT, K>;
@@ -1688,7 +1712,7 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
     uint32_t rnk2[(K + 1) / 2];
     {
         uint32_t rnk[K];
-        rank_in_wave<E, 8, K, 1>(e, rnk, my_wcnt, start_bit);
+        rank_in_wave<E, 8, K, RANK>(e, rnk, my_wcnt, start_bit);
 #pragma unroll
         for (int j = 0; j < K; j += 2) rnk2[j >> 1] = rnk[j] | ((j + 1 < K ? rnk[j + 1] : 0u) << 16);
     }
@@ -1795,7 +1819,7 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
 // Between pass B and the finish: workgroup b turns bucket b's final counts (the last status row of chain b) into the
 // segments' sizes and output offsets; the last workgroup publishes the mode word and the host's hint.
 // As in the keys-only form, the safety net runs in this kernel when the overflow flag is set.
-template <typename E, int TILE, int NT, int K>
+template <typename E, int TILE, int NT, int K, int RANK = 1>
 __global__ __launch_bounds__(NT) void msd2s_offsets_kernel(const uint32_t* __restrict__ status_a, uint32_t rows_per_chain_a, uint32_t slice,
                                                             uint32_t pieces,
                                                             const uint32_t* __restrict__ status_b, uint32_t rows_per_chain_b,
@@ -1873,7 +1897,7 @@ __global__ __launch_bounds__(NT) void msd2s_offsets_kernel(const uint32_t* __res
                 if (!grid_barrier(bar, target, gridDim.x, fault)) return;
             }
         }
-        net_sort<E, NT, K>(data, tmp, n, ctable, bar, fault, smem, (int)place->sort_bits, soa_keys ? nullptr : dict, stats, target);
+        net_sort<E, NT, K, RANK>(data, tmp, n, ctable, bar, fault, smem, (int)place->sort_bits, soa_keys ? nullptr : dict, stats, target);
         if constexpr (sizeof(E) == 8) {
             if (soa_keys) {   // the sort's last phase ends with a grid barrier: `data` is complete
                 for (size_t i = (size_t)blockIdx.x * NT + (size_t)t; i < n; i += (size_t)gridDim.x * NT) {

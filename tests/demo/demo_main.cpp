@@ -187,6 +187,113 @@ void demoFillCopy(Device* d, Pprims& p)
     printf("[       %s ] Demo.FillCopy (%.0f ms)\n", g_failed > before ? "FAIL" : "OK", now_ms() - t0);
 }
 
+// Demo.SortWideValues: separate key and value buffers, u32 keys + u64 values and u64 keys + u64 values, value =
+// {hash of the key, source index}: sorted by key, every value beside its key, equal keys in source order (stable).
+void demoSortWideValues(Device* d, Pprims& p)
+{
+    printf("[ RUN      ] Demo.SortWideValues\n");
+    const double t0 = now_ms();
+    const int before = g_failed;
+    const int sizes[] = {1, 255, 4097, 100003, (1 << 21) + 17};
+    for (int n : sizes) {
+        for (int wide_keys = 0; wide_keys < 2; ++wide_keys) {
+            std::vector<u64> k64(n), v(n);
+            std::vector<u32> k32(n);
+            srand(123 + n);
+            for (int i = 0; i < n; ++i) {
+                const u32 r = ((u32)rand() << 16) ^ (u32)rand();
+                k32[i] = r & 0x00ffffffu;                                   // duplicates: stability is visible
+                k64[i] = ((u64)(r & 0xffu) << 40) | (u64)(r >> 20);         // ties in either dword
+                const u64 key = wide_keys ? k64[i] : (u64)k32[i];
+                v[i] = ((key * 0x9E3779B1ull) << 32) | (u64)(u32)i;
+            }
+            Buffer<u64> vb(d, n);
+            vb.write(v.data(), n);
+            std::vector<u64> gk(n), gv(n);
+            if (wide_keys) {
+                Buffer<u64> kb(d, n);
+                kb.write(k64.data(), n);
+                p.radixSort(d, kb, vb, n);
+                kb.read(gk.data(), n);
+                vb.read(gv.data(), n);
+                DeviceUtils::waitForCompletion(d);
+            } else {
+                Buffer<u32> kb(d, n);
+                kb.write(k32.data(), n);
+                p.radixSort(d, kb, vb, n);
+                std::vector<u32> g32(n);
+                kb.read(g32.data(), n);
+                vb.read(gv.data(), n);
+                DeviceUtils::waitForCompletion(d);
+                for (int i = 0; i < n; ++i) gk[i] = g32[i];
+            }
+            bool ok = true;
+            for (int i = 0; i < n; ++i) {
+                ok &= (gv[i] >> 32) == ((gk[i] * 0x9E3779B1ull) & 0xffffffffull);            // the value still belongs to its key
+                const u32 src = (u32)gv[i];
+                ok &= src < (u32)n && (wide_keys ? k64[src] : (u64)k32[src]) == gk[i];          // ... and came from that position
+                if (i) ok &= gk[i - 1] < gk[i] || (gk[i - 1] == gk[i] && (u32)gv[i - 1] < src); // sorted, stable
+            }
+            check(ok, wide_keys ? "u64 keys + u64 values" : "u32 keys + u64 values", n);
+        }
+    }
+    printf("[       %s ] Demo.SortWideValues (%.0f ms)\n", g_failed > before ? "FAIL" : "OK", now_ms() - t0);
+}
+
+// Demo.BufferUtils (Adl.h:224-248) and SyncObject (AdlKernel.h:45-54): a host buffer seen from the device and back, a device
+// buffer seen from the host, in-place variants, and an event recorded behind a copy.
+void demoBufferUtils(Device* d)
+{
+    printf("[ RUN      ] Demo.BufferUtils\n");
+    const double t0 = now_ms();
+    const int before = g_failed;
+    Device* host = DeviceUtils::allocate(TYPE_HOST);
+    const int n = 100003;
+    {
+        HostBuffer<u32> h(host, n);
+        for (int i = 0; i < n; ++i) h[i] = (u32)i * 2654435761u;
+        // host buffer -> device (copied), sorted there, copied back by unmap
+        Buffer<u32>* onDev = BufferUtils::map<TYPE_CL, true>(d, (const Buffer<u32>*)&h);
+        check(onDev != (Buffer<u32>*)&h && onDev->getType() == TYPE_CL && (int)onDev->getSize() == n, "map to the device", n);
+        {
+            Pprims p;
+            p.radixSort(d, *onDev, n);
+        }
+        BufferUtils::unmap<true>(onDev, (const Buffer<u32>*)&h);
+        bool ok = true;
+        for (int i = 1; i < n; ++i) ok &= h[i - 1] <= h[i];
+        check(ok, "sorted through map / unmap", n);
+        // device buffer seen from the host: a view of its mapping; writes go back at unmap
+        Buffer<u32> dev(d, n);
+        dev.write(h.begin(), n);
+        Buffer<u32>* onHost = BufferUtils::map<TYPE_HOST, true>(host, (const Buffer<u32>*)&dev);
+        DeviceUtils::waitForCompletion(d);
+        ok = onHost->getType() == TYPE_HOST;
+        for (int i = 0; i < n; ++i) ok &= onHost->m_ptr[i] == h[i];
+        onHost->m_ptr[7] = 0xdeadbeefu;
+        BufferUtils::unmap<true>(onHost, (const Buffer<u32>*)&dev);
+        DeviceUtils::waitForCompletion(d);
+        u32 seven = 0;
+        SyncObject ev(d);
+        check(DeviceUtils::isComplete(&ev), "an event that was never recorded is complete", 0);
+        dev.read(&seven, 1, 7, &ev);
+        DeviceUtils::waitForCompletion(&ev);                       // waits for the copy only
+        check(ok && seven == 0xdeadbeefu && DeviceUtils::isComplete(&ev), "host view of a device buffer + SyncObject", n);
+        // same type: map hands back the buffer itself; in-place variants use the caller's buffer
+        check(BufferUtils::map<TYPE_CL, true>(d, (const Buffer<u32>*)&dev) == &dev, "map of a native buffer is the buffer", n);
+        Buffer<u32> scratch(d, n);
+        Buffer<u32>* in = BufferUtils::mapInplace<TYPE_CL, true>(d, &scratch, (const Buffer<u32>*)&h);
+        check(in == &scratch, "mapInplace uses the caller's buffer", n);
+        scratch.fill((void*)&seven, 4);
+        BufferUtils::unmapInplace<true>(in, (const Buffer<u32>*)&h);
+        ok = true;
+        for (int i = 0; i < n; ++i) ok &= h[i] == 0xdeadbeefu;
+        check(ok, "unmapInplace copies back", n);
+    }
+    DeviceUtils::deallocate(host);
+    printf("[       %s ] Demo.BufferUtils (%.0f ms)\n", g_failed > before ? "FAIL" : "OK", now_ms() - t0);
+}
+
 // Demo.ShardedSort: G shards of the reference's random data (one srand seed per shard), keys and {key, value} pairs,
 // sorted across G devices; every rank's slice is downloaded and the concatenation compared with the host's sort.
 void demoShardedSort(int G)
@@ -279,7 +386,9 @@ int main(int argc, char** argv)
         demoSortKeyValue(d, p);
         demoFillCopy(d, p);
         if (!host) demoScan(d, p);   // scan has no host path in the reference either (Pprims.cpp:124-127)
+        if (!host) demoSortWideValues(d, p);
     }
+    if (!host) demoBufferUtils(d);
     DeviceUtils::deallocate(d);
     if (!host && gpus > 0) demoShardedSort(gpus);
     g_failed += adl_assert_failures();

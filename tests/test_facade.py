@@ -68,6 +68,8 @@ def test_demo_on_the_hip_device(built):
     assert r.stdout.count("test ") == 33          # 11 sizes x 3 primitives, Scan includes 1024K
     assert re.search(r"OK \] Demo\.Scan", r.stdout)
     assert re.search(r"OK \] Demo\.FillCopy", r.stdout)
+    assert re.search(r"OK \] Demo\.SortWideValues", r.stdout)   # 64-bit values / keys through Pprims::radixSort(keys, values)
+    assert re.search(r"OK \] Demo\.BufferUtils", r.stdout)      # BufferUtils::map / unmap across device types, SyncObject events
 
 
 @pytest.mark.gpu

@@ -2094,3 +2094,81 @@ def test_partition_top_byte_one_lookback_pass_equals_three_kernels(dev):
                 dev.setParam("partition.lookback", 1)
                 for b in (src, dst, tot, work):
                     b.release()
+
+
+def test_lean_scratch_level_for_pairs_keeps_the_large_sort(dev):
+    """Level 2 of adlhip_radix_sort_scratch_bytes_for for {key, value} pairs (review, round 3, item 8): the stable form with
+    statistical head-room only (mean + 8 sd / + 7.5 sd instead of + 50 %) -- 64 Mi pairs within 1.3 GB instead of 1.7.  Evenly
+    spread keys take the large sort's kernels with that buffer; keys that are 20 % denser in one half take the net; both bit-exact."""
+    lib = _lib.load()
+
+    def sizes(kind, n, bits, level):
+        tb, wb = ctypes.c_size_t(), ctypes.c_size_t()
+        check(lib.adlhip_radix_sort_scratch_bytes_for(dev._h, kind, n, bits, level, ctypes.byref(tb), ctypes.byref(wb)), "scratch")
+        return tb.value, wb.value
+
+    assert sizes(1, 1 << 26, 32, 0)[1] < sizes(1, 1 << 26, 32, 2)[1] <= 1300 * 1000 * 1000 < sizes(1, 1 << 26, 32, 1)[1]
+    n = (1 << 23) + 77
+    _, lean = sizes(1, n, 32, 2)
+    _, full = sizes(1, n, 32, 1)
+    assert lean < 0.85 * full
+    pairs = oracle.pairs_kv32(n, seed=12) & np.uint64(0xffffffff00ffffff)          # 24-bit keys: duplicates, stability visible
+    k = (pairs & np.uint64(0xffffffff)).astype(np.uint32)
+    skew = np.where(np.arange(n) % 10 < 2, k >> np.uint32(1), k).astype(np.uint64) | (pairs & np.uint64(0xffffffff00000000))
+    data, tmp, work = Buffer(dev, n, np.uint64), Buffer(dev, n, np.uint64), Buffer(dev, lean, np.uint8)
+    try:
+        runs0 = dev.getParam("stat.net_runs")
+        for name, host, net in (("even", pairs, 0), ("denser lower half", skew, 1)):
+            data.write(host)
+            dev.toggleProfiling(True); dev.profile(reset=True)
+            check(lib.adlhip_radix_sort_kv32(dev._h, data.ptr(), tmp.ptr(), work.ptr(), lean, n, 32), "sort")
+            prof = dev.profile(reset=True); dev.toggleProfiling(False)
+            assert set(prof) == LARGE_PAIRS, (name, prof)
+            assert np.array_equal(data.toHost(), oracle.sort_kv32(host)), name
+            assert dev.getParam("stat.net_runs") - runs0 == net, name
+            runs0 += net
+        dev.checkFault()
+    finally:
+        dev.toggleProfiling(False)
+        for b in (data, tmp, work):
+            b.release()
+
+
+def test_rank0_pairs_take_the_stable_large_sort(dev):
+    """"sort.rank" = 0 -- no reliance on the lane order of colliding returning DS atomics -- used to send every sort to the per-digit
+    passes.  Pairs now keep the stable large sort: its look-back passes, its wave-per-segment finish and its safety net have
+    ballot-ranked variants (review, round 3, item 5).  Stability-revealing inputs (few distinct keys, value = index), sizes across
+    the finish's tiles, SoA arrays, a skewed input through the net; rank 1 and rank 0 must agree bit for bit with the oracle."""
+    p = Pprims()
+    try:
+        for n in ((1 << 21) + 33, (1 << 23) + 5, (1 << 25) + 77, (1 << 26)):
+            for name, mask in (("24-bit keys", 0xffffffff00ffffff), ("256 distinct keys", 0xffffffff000000ff)):
+                pairs = oracle.pairs_kv32(n, seed=n & 0xff) & np.uint64(mask)
+                want = oracle.sort_kv32(pairs)
+                for rank in (0, 1):
+                    set_algo(dev, (-1, 8, -1, rank))
+                    got, prof = _profiled(dev, lambda: gpu_sort_kv(dev, p, pairs))
+                    if name == "24-bit keys":
+                        assert set(prof) == LARGE_PAIRS, (n, rank, prof)        # the large sort, whichever way it ranks
+                    assert np.array_equal(got, want), (n, name, rank)
+        # SoA arrays and a skewed input (the net) with rank 0
+        set_algo(dev, (-1, 8, -1, 0))
+        n = (1 << 22) + 11
+        k = oracle.keys_u32(n, seed=3) & np.uint32(0x0000ffff)
+        v = np.arange(n, dtype=np.uint32)
+        kb, vb = Buffer(dev, n, np.uint32), Buffer(dev, n, np.uint32)
+        kb.write(k); vb.write(v)
+        p.radixSortSoA(dev, kb, vb, n)
+        order = np.argsort(k, kind="stable")
+        assert np.array_equal(kb.toHost(), k[order]) and np.array_equal(vb.toHost(), v[order])
+        kb.release(); vb.release()
+        runs = dev.getParam("stat.net_runs")
+        skew = np.where(np.arange(n) % 10 != 0, k >> np.uint32(9), k | np.uint32(0xffff0000)).astype(np.uint64) | (v.astype(np.uint64) << np.uint64(32))
+        dev.setParam("sort.msd2", 2)
+        assert np.array_equal(gpu_sort_kv(dev, p, skew), oracle.sort_kv32(skew))
+        assert dev.getParam("stat.net_runs") == runs + 1
+        dev.checkFault()
+    finally:
+        dev.setParam("sort.msd2", 1)
+        set_algo(dev, (-1, 8, -1))
+        p.close()
