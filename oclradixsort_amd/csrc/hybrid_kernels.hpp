@@ -562,22 +562,42 @@ __device__ __forceinline__ void wave_sort_rows(const S* __restrict__ src, E* __r
         // large tiles of the big segments (K = 40, 80: one to four waves per CU) would sit out one LDS round trip per element,
         // so they take their slots eight at a time
         if constexpr (RANK == 0) {
+            // two sweeps over the rows so that nothing waits for an LDS round trip per row: (1) the peers of every row by ballots; the
+            // LOWEST peer reserves the group's slots with one returning add -- within one instruction only one lane per digit adds,
+            // so no two lanes collide and the order of colliding lanes never matters; rows follow each other in issue order --
+            // (2) every lane fetches its group's start from that lane (ds_bpermute) and stores its element
+            // (eight rows at a time: with all R rows' values live the kernel loses its occupancy)
+            constexpr int RB = 8;
 #pragma unroll
-            for (int j = 0; j < R; ++j) {
-                if (j < F || j * 64 < rem) {
-                    const uint32_t dg = digit(e[j]);
-                    const uint64_t act = __ballot(true);   // the lanes that hold an item of this row
-                    uint64_t peers = act;
+            for (int j0 = 0; j0 < R; j0 += RB) {
+                uint32_t base[RB], info[RB];   // info = leader lane << 8 | peers below
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const bool bit = (dg >> b) & 1u;
-                        const uint64_t bal = __ballot(bit);
-                        peers &= bit ? bal : ~bal;
+                for (int jj = 0; jj < RB; ++jj) {
+                    const int j = j0 + jj;
+                    base[jj] = 0u;
+                    info[jj] = 0u;
+                    if (j < R && (j < F || j * 64 < rem)) {
+                        const uint32_t dg = digit(e[j < R ? j : R - 1]);
+                        uint64_t peers = __ballot(true);   // the lanes that hold an item of this row
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) {
+                            const bool bit = (dg >> b) & 1u;
+                            const uint64_t bal = __ballot(bit);
+                            peers &= bit ? bal : ~bal;
+                        }
+                        const uint32_t below = mbcnt64(peers);
+                        info[jj] = ((uint32_t)__builtin_ctzll(peers) << 8) | below;
+                        if (below == 0u)
+                            base[jj] = __hip_atomic_fetch_add(&cnt[dg], (uint32_t)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
-                    const uint32_t below = mbcnt64(peers);
-                    const uint32_t base = __hip_atomic_load(&cnt[dg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    if (below == 0u) __hip_atomic_store(&cnt[dg], base + (uint32_t)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    buf[base + below] = e[j];
+                }
+#pragma unroll
+                for (int jj = 0; jj < RB; ++jj) {
+                    const int j = j0 + jj;
+                    if (j < R && (j < F || j * 64 < rem)) {
+                        const uint32_t start = (uint32_t)__shfl((int)base[jj], (int)(info[jj] >> 8));
+                        buf[start + (info[jj] & 0xffu)] = e[j < R ? j : R - 1];
+                    }
                 }
             }
         }

@@ -368,16 +368,26 @@ __device__ __forceinline__ void rank_in_wave(const E (&e)[K], uint32_t (&rnk)[K]
             }
         }
     } else {
+        // (round 4) the lowest peer alone adds -- one lane per digit and instruction, so nothing collides and no order is assumed --
+        // with a RETURNING add; the K adds go out back to back (items in issue order) and the peers fetch their group's value from
+        // that lane afterwards (ds_bpermute).  Round 3 read the counter in every peer and waited for it item by item.
+        // (four items at a time: with all K in flight the kernel spilled and ran twice as long)
+        constexpr int B = K % 4 == 0 ? 4 : (K % 2 == 0 ? 2 : 1);
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const uint32_t d = digit_of<NBITS>(e[j], start_bit);
-            const uint64_t m = match_digit<NBITS>(d);
-            const uint32_t below = mbcnt64(m);
-            const uint32_t cnt = (uint32_t)__popcll(m);
-            const uint32_t old = __hip_atomic_load(&my_wcnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (below == 0u)
-                __hip_atomic_fetch_add(&my_wcnt[d], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            rnk[j] = old + below;
+        for (int j0 = 0; j0 < K; j0 += B) {
+            uint32_t old[B], info[B];   // info = leader lane << 8 | peers below
+#pragma unroll
+            for (int jj = 0; jj < B; ++jj) {
+                const uint32_t d = digit_of<NBITS>(e[j0 + jj], start_bit);
+                const uint64_t m = match_digit<NBITS>(d);
+                const uint32_t below = mbcnt64(m);
+                info[jj] = ((uint32_t)__builtin_ctzll(m) << 8) | below;
+                old[jj] = 0u;
+                if (below == 0u)
+                    old[jj] = __hip_atomic_fetch_add(&my_wcnt[d], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+#pragma unroll
+            for (int jj = 0; jj < B; ++jj) rnk[j0 + jj] = (uint32_t)__shfl((int)old[jj], (int)(info[jj] >> 8)) + (info[jj] & 0xffu);
         }
     }
 }
