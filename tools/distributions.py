@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sort time on non-uniform inputs (64Mi u32): sorted, reverse, all-equal, 16 / 256 / 4096 distinct values, low byte only, one heavy top byte.
-Columns: the automatic choice (large sort; first sort of a fresh handle = its safety net on keys that do not fit the slabs,
-and the 8th sort = after the hint has arrived), then forced (algo, rank) pairs."""
+Columns: the automatic choice -- the first and the 8th sort of a FRESH handle whose scratch was reserved beforehand (round 4: nothing is
+remembered between sorts, so the two differ only by first-use costs of the kernels' code) -- then forced (algo, rank) pairs."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,7 +28,8 @@ print("%-12s %s" % ("input", "ms/sort by (algo, rank)"))
 for kind in ("uniform", "sorted", "reverse", "all_equal", "16_values", "low_byte", "256_values", "heavy_top_byte", "4096_values"):
     make(kind)
     row = []
-    d2 = DeviceUtils.allocate(); p2 = Pprims()   # a fresh handle: no hints yet
+    d2 = DeviceUtils.allocate(); p2 = Pprims()   # a fresh handle
+    p2.reserve(d2, 0, n)
     w2 = Buffer(d2, n, np.uint32)
     times = []
     for t in range(8):
