@@ -25,7 +25,8 @@ for n in (1 << 18, 1 << 20):
     for nm, k in cases.items():
         k = k.astype(np.uint32)
         res = []
-        for mid in (1, 0):
+        mids = (1, 0, 2, 3) if "--forced" in sys.argv else (1, 0)   # 2 / 3: every sort through the two- / three-launch form (and its net)
+        for mid in mids:
             d = DeviceUtils.allocate(); p = Pprims()
             d.setParam("sort.mid", mid)
             bufs = [Buffer(d, n, np.uint32) for _ in range(8)]
@@ -41,4 +42,4 @@ for n in (1 << 18, 1 << 20):
             res.append((total / 48 * 1e3, ok))
             for b in bufs: b.release()
             p.close(); DeviceUtils.deallocate(d)
-        print("  %-30s mid=1 %8.1f us %s   mid=0 %8.1f us %s" % (nm, res[0][0], "OK" if res[0][1] else "WRONG", res[1][0], "OK" if res[1][1] else "WRONG"), flush=True)
+        print("  %-30s " % nm + "   ".join("mid=%d %8.1f us %s" % (m, r[0], "OK" if r[1] else "WRONG") for m, r in zip(mids, res)), flush=True)
