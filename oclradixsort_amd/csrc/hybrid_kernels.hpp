@@ -35,12 +35,17 @@ namespace adlhip {
 // All workgroups are resident at once (at most one per CU is needed and each takes ~1/8 of a CU's LDS); every
 // spin is bounded and raises the device fault word when it gives up.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t& target, uint32_t wgs, uint32_t* fault)
+// data_fence = false: the barrier orders only what went through agent-scope atomics (write-through stores that are complete at the
+// s_waitcnt, loads that pass every cache): the digit table and the totals of the net's count and scan phases.  The two fences --
+// write the XCD's L2 back, then drop what it holds -- cost ~10 us a barrier (the mid-size net at 1 Mi keys: twelve barriers, 200 us)
+// and are needed only where ordinary stores must become visible: behind a scatter phase.
+__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t& target, uint32_t wgs, uint32_t* fault, bool data_fence = true)
 {
     __shared__ uint32_t ok;
+    if (!data_fence) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every thread's write-through stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this workgroup's stores leave the XCD's L2
+        if (data_fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this workgroup's stores leave the XCD's L2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         target += wgs;
@@ -50,7 +55,7 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t& target
             __builtin_amdgcn_s_sleep(2);
         }
         if (!good) raise_fault(fault, 0x80000u);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop what this CU's L1 holds of other workgroups' data
+        if (data_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop what this CU's L1 holds of other workgroups' data
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ok = good;
     }
@@ -150,6 +155,10 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
     uint32_t target = target0;   // the barrier counter is zero on entry unless the caller has used it already
     E* src = data;
     E* dst = tmp;
+    // the digit table and the totals cross workgroups (and XCDs) through agent-scope atomics: no cache holds them, so the barriers of
+    // the count and scan phases need no fence (grid_barrier, data_fence = false)
+    auto tab_ld = [](const uint32_t* p) -> uint32_t { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto tab_st = [](uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     // key_bits: 32 (u32 keys, pairs), 64 (u64 keys), or the sortBits of a partial sort (a multiple of 4: the last digit is then 4
     // bits wide, and an odd number of passes leaves the result in tmp -- copied back, Pprims.cpp:400-403)
     for (int sb = 0; sb < key_bits; sb += 8) {
@@ -163,32 +172,32 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
         if (tid < 256) {
             uint32_t c = 0u;
             for (int i = 0; i < NW; ++i) c += hist[i * 256 + tid];
-            table[(size_t)tid * wgs + wg] = c;
+            tab_st(&table[(size_t)tid * wgs + wg], c);
         }
-        if (!grid_barrier(bar, target, wgs, fault)) return;
+        if (!grid_barrier(bar, target, wgs, fault, false)) return;
         // ---- workgroup d scans row d (rows d, d + wgs, ... when there are fewer workgroups than digits) ---------------
         for (uint32_t d = wg; d < 256u; d += wgs) {
             uint32_t carry = 0u;
             for (uint32_t base = 0; base < wgs; base += (uint32_t)NT) {
                 const uint32_t j = base + (uint32_t)tid;
-                const uint32_t v = j < wgs ? table[(size_t)d * wgs + j] : 0u;
+                const uint32_t v = j < wgs ? tab_ld(&table[(size_t)d * wgs + j]) : 0u;
                 uint32_t tot;
                 const uint32_t ex = block_excl_scan_u32<NT>(v, s_wsum, &tot);
-                if (j < wgs) table[(size_t)d * wgs + j] = carry + ex;
+                if (j < wgs) tab_st(&table[(size_t)d * wgs + j], carry + ex);
                 carry += tot;
             }
-            if (tid == 0) totals[d] = carry;
+            if (tid == 0) tab_st(&totals[d], carry);
         }
-        if (!grid_barrier(bar, target, wgs, fault)) return;
+        if (!grid_barrier(bar, target, wgs, fault, false)) return;
         // ---- scatter this workgroup's tiles, carrying per-digit offsets from tile to tile ------------------------------
         {
-            const uint32_t tot_d = tid < 256 ? totals[tid] : 0u;
+            const uint32_t tot_d = tid < 256 ? tab_ld(&totals[tid]) : 0u;
             // every key has the same digit here (a constant byte: small ranges, few-valued keys): the pass would move nothing
             // (the next pass's count phase writes this workgroup's own table column only, and nobody rewrites the totals before
             // the next barrier, so the barrier that ends a pass is not needed either)
             if (__syncthreads_or(tid < 256 && tot_d == n)) continue;
             const uint32_t base_d = block_excl_scan_u32<NT>(tot_d, s_wsum, nullptr);
-            uint32_t carry = tid < 256 ? base_d + table[(size_t)tid * wgs + wg] : 0u;
+            uint32_t carry = tid < 256 ? base_d + tab_ld(&table[(size_t)tid * wgs + wg]) : 0u;
             const AosIO<E> io{src, dst};
             for (uint32_t t = t0; t < t1; ++t) {
                 const uint32_t tb = t * (uint32_t)C::TILE;
