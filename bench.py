@@ -510,6 +510,30 @@ def main():
                 others["config3_rank0_ballot_ranking"] = {"error": repr(e)[:300]}
             finally:
                 d.setParam("sort.rank", d.getParam("sort.lds_ordered"))
+        # SURVEY f3, second half: 64 Mi u32 keys with u64 VALUES on separate arrays (index sort + one gather, adlhip_radix_sort_soa)
+        if n == N_KEYS and not args.no_other_configs:
+            try:
+                nn = 1 << 26
+                kb = Buffer(d, nn, np.uint32)
+                vb = Buffer(d, nn, np.uint64)
+                ts = []
+                for t in range(3):
+                    kb.generate(nn, seed=980 + t)
+                    vb.generate(nn, seed=990 + t, kind=2)
+                    DeviceUtils.waitForCompletion(d)
+                    s5 = Stopwatch(d)
+                    s5.start()
+                    p.radixSortSoA(d, kb, vb, nn)
+                    s5.stop()
+                    ts.append(s5.getMs())
+                got = kb.toHost()
+                others["f3_u32_keys_u64_values_64Mi"] = {"value": nn / min(ts[1:]) / 1e6, "unit": "Gpairs/s", "ms_per_sort": min(ts[1:]), "elements": nn,
+                                                         "keys_sorted": bool(np.all(got[1:] >= got[:-1]))}
+                del got
+                kb.release()
+                vb.release()
+            except Exception as e:
+                others["f3_u32_keys_u64_values_64Mi"] = {"error": repr(e)[:300]}
         out["other_configs"] = others
         # The same sort on keys that are NOT uniform (beside the metric, not part of it): the large sort's slabs give every bucket the
         # same room, so such keys end in its safety net (counting sort for few distinct values, LSD passes otherwise) -- the bench must
