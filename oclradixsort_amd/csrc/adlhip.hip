@@ -1040,8 +1040,8 @@ uint32_t msd2_seg_shift(size_t n, bool bin_finish)
 
 
 // head-room of a first-pass bucket slab over the mean bucket, in per cent: 50 at full speed; the lean work size
-// (adlhip_radix_sort_scratch_bytes_for, level 2) takes 12 -- 64 Mi u32 keys then need 307 MB of work instead of 451, and keys whose
-// density varies by more than ~10 % over the key range go to the safety net (and, by the handle's hints, to the one-sweep passes)
+// (adlhip_radix_sort_scratch_bytes_for, level 2) takes 12 -- 64 Mi u32 keys then need 306 MB of work instead of 451, and keys whose
+// density varies by more than ~10 % over the key range are sorted by the safety net inside the sort
 constexpr int kFullHeadroomPct = 50, kLeanHeadroomPct = 12;
 
 // Workgroups of the kernels that host the safety net (512 threads, one tile of the one-sweep pass's size in LDS: two per CU).
@@ -1641,7 +1641,7 @@ int sort_entry(adlhip_device* d, int elem_kind, E* data, E* tmp, void* work, siz
                 work, work_bytes);
     const std::vector<PassPlan> plan = plan_passes(sort_bits, d->digit_bits);
     // one workgroup, one launch -- except u32 keys just below its limit, which the two-launch mid-size sort does faster (while
-    // the handle's hints do not keep them off it)
+    // the mid-size sort's own reports do not keep them off it, choose_mid_form)
     const bool small = d->sort_algo < 0 && n <= kSmallMax;
     const bool small_mid = small && sizeof(E) == 4 && sort_bits == max_bits && n > mid_min_u32() && (d->mid_path == 2 || d->mid2_skip == 0);
     if (small && !small_mid) return small_sort<E>(d, data, n, plan);
@@ -1953,7 +1953,7 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         return fail("cannot allocate the mid-size sort's histogram area");
     }
     // the large sort's handle-owned words (cursors, flags: 270 KB), zero between sorts -- allocated here rather than by a handle's
-    // first large sort, which then only has its probe to wait for
+    // first large sort
     if (hipMalloc(&d->d_msd2, (8192 + 65536 + 64) * 4) != hipSuccess ||
         hipMemsetAsync(d->d_msd2, 0, (8192 + 65536 + 64) * 4, d->stream) != hipSuccess ||
         hipMemsetAsync(d->d_msd2 + 8192 + 65536 + 10, 0xff, 8, d->stream) != hipSuccess) {   // the sample's AND words: all ones when idle
@@ -2508,7 +2508,7 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
         d->mid_path = value;
     } else if (!strcmp(name, "sort.msd2")) {
         if (value < 0 || value > 5)
-            return fail("sort.msd2 must be 0 (off), 1 (on), 2 (always, whatever the hints say; forms by size), 3 (always the stable passes), "
+            return fail("sort.msd2 must be 0 (off), 1 (on), 2 (always, from 1 Mi elements; forms by size), 3 (always the stable passes), "
                         "4 (always the cursor passes for whole keys) or 5 (always the hybrid form for whole keys)");
         d->msd2_path = value;
     } else if (!strcmp(name, "sort.persist")) {

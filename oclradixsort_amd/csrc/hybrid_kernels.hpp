@@ -1106,7 +1106,7 @@ __device__ __forceinline__ Msd2Placement msd2_placement(const uint32_t* __restri
     p.prefix = p.top < 64 ? (o >> p.top) : 0ull;
     return p;
 }
-// Where the probe reads sample k of 16384 (n >= 16384): somewhere inside the k-th 16384th of the array (a fixed stride would see
+// Where the net's dictionary sampling (dict_sample_build; rounds 2-3: the key probe) reads sample k of 16384 (n >= 16384): somewhere inside the k-th 16384th of the array (a fixed stride would see
 // one phase of periodic keys only).  The offset inside the cell is a 24-bit hash scaled by multiply-and-shift, NOT `hash % cell`:
 // the compiler expands a remainder of operands it knows to fit 24 bits through float (v_rcp_iflag_f32, one upward correction),
 // which overshoots the quotient for some operands (n = 7726351: 13 of the 16384 samples), the "remainder" wraps to ~2^24 and
@@ -1434,10 +1434,10 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
 // second pass and the finish: workgroup b turns bucket b's 256 cursors into output offsets (bucket base = scan of the first
 // pass's cursors), saves the counts for the finish, clears the cursors for the next sort (they belong to the device handle),
 // and the last workgroup publishes the mode word: 0 = every run fitted its slab; else 1 -- the finish returns at once, and the
-// workgroups of THIS kernel go on to sort the untouched input with the cooperative LSD sort (slowly: it is the safety net; the
-// host's hint keeps such inputs off this path).
+// workgroups of THIS kernel go on to sort the untouched input with net_sort (counting sort for few distinct values, else the
+// cooperative LSD passes).  Nothing is told to the host: the same input takes the same path and time at every call.
 // ------------------------------------------------------------------------------------------
-// The safety net lives in this kernel too: its 256 workgroups are all resident, so when the overflow flag is set they go on to
+// The safety net lives in this kernel too: its workgroups (512 of 512 threads, two per CU) are all resident, so when the overflow flag is set they go on to
 // sort the untouched input with the cooperative LSD sort (a launch of its own that returns at once cost 5-6 us per sort).
 template <typename E, int NT, int K>
 __global__ __launch_bounds__(NT) void msd2_offsets_kernel(uint32_t* cursors_a, uint32_t* cursors_b, uint32_t* flag, uint32_t* done,
@@ -1846,7 +1846,7 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
 }
 
 // Between pass B and the finish: workgroup b turns bucket b's final counts (the last status row of chain b) into the
-// segments' sizes and output offsets; the last workgroup publishes the mode word and the host's hint.
+// segments' sizes and output offsets; the last workgroup publishes the mode word.
 // As in the keys-only form, the safety net runs in this kernel when the overflow flag is set.
 template <typename E, int TILE, int NT, int K, int RANK = 1>
 __global__ __launch_bounds__(NT) void msd2s_offsets_kernel(const uint32_t* __restrict__ status_a, uint32_t rows_per_chain_a, uint32_t slice,
