@@ -17,7 +17,10 @@ from oclradixsort_amd._lib import check
 ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=60.0)
 ap.add_argument("--skip-before", type=int, default=0, help="replay: draw the first iterations without running them")
 ap.add_argument("--stop-after", type=int, default=1 << 30); ap.add_argument("--verbose", action="store_true")
-ap.add_argument("--seed", type=int, default=2026); args = ap.parse_args()
+ap.add_argument("--seed", type=int, default=2026)
+ap.add_argument("--mix-rank", action="store_true", help="also draw sort.rank per sort (0 = ballot ranking: the stable large sort's ballot variants)")
+args = ap.parse_args()
+mix_rng = np.random.RandomState(args.seed + 1)
 skip_before, verbose = args.skip_before, args.verbose
 d = DeviceUtils.allocate(); p = Pprims()
 d2 = DeviceUtils.allocate(); selftests = 0
@@ -37,6 +40,7 @@ while time.time() < t_end and it < args.stop_after:
     algo = int(rng.choice([0, 0, 1, -1, -1, -1])); bits = int(rng.choice([8, 8, 8, 4])); tile = int(rng.choice([-1, -1, 0, 1, 2, 5]))
     if algo < 0: bits, tile = 8, -1   # what the automatic paths run with
     d.setParam("sort.algo", algo); d.setParam("sort.digit_bits", bits); d.setParam("sort.tile", tile)
+    if args.mix_rank: d.setParam("sort.rank", int(mix_rng.choice([1, 1, 0])))   # ballot ranking on a third of the sorts (own generator: replays stay aligned)
     d.setParam("sort.msd2", int(rng.choice([1, 1, 1, 2, 3, 4, 5])))   # automatic or a forced form
     dist = rng.choice(["uniform", "lowbits", "fewvals", "sortedish", "shifted", "shifted", "heavy", "vals4096"])
     shift = int(rng.randint(1, 20))
