@@ -1181,8 +1181,13 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
     uint32_t* __restrict__ s_wcnt = reinterpret_cast<uint32_t*>(smem + C::OFF_WCNT);   // [NW][BINS]
     uint32_t* __restrict__ s_goff = reinterpret_cast<uint32_t*>(smem + C::OFF_GOFF);   // [BINS]
     if (a.zero_me && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.zero_me, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if constexpr (PASS >= 1) {   // a run has outgrown its slab: the net will sort (net_sort), nothing written from here on is read
-        if (__hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    // a run has outgrown its slab: the net will sort (net_sort), nothing written from here on is read.  The flag is requested here and
+    // looked at behind the tile's key loads (below), so that its round trip hides behind theirs
+    // (ONE thread's view, handed to all through LDS behind the ranking's barrier: the flag can rise between two waves' loads, and a
+    // workgroup of which some waves have left would go on with stale counters)
+    uint32_t give_up = 0u;
+    if constexpr (PASS >= 1) {
+        if (threadIdx.x == 0) give_up = __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     uint32_t base, valid, cursor_base = 0u;
     uint32_t lin = 0u;   // PASS == 3: index of the tile's first element if the tile lies inside one sub-slab, else ~0
@@ -1340,7 +1345,13 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
     for (int j = 0; j < (K + 1) / 2; ++j) asm volatile("" : "+v"(rnk2[j]));
 #pragma unroll
     for (int j = 0; j < K; ++j) asm volatile("" : "+v"(e[j]));
+    if constexpr (PASS >= 1) {
+        if (threadIdx.x == 0) reinterpret_cast<uint32_t*>(smem + C::OFF_MISC)[8] = give_up;
+    }
     __syncthreads();
+    if constexpr (PASS >= 1) {
+        if (reinterpret_cast<const uint32_t*>(smem + C::OFF_MISC)[8]) return;   // every wave leaves, or none
+    }
     // ---- every wave: counts of all waves for its lanes' digits -> tile offsets -> its own (wave, digit) positions -------------
     u32x4 cnt4 = {0u, 0u, 0u, 0u};
     u32x4 toff4 = {0u, 0u, 0u, 0u};
@@ -1602,19 +1613,22 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
     // workgroups that run at the same time work on the same few buckets and write into the same few hundred segment slabs
     // (chain = i % 256, which spreads every moment's writes over all 65536 slabs, measured 0.299 vs 0.272 ms at 64 Mi pairs and
     // 0.637 vs 0.527 ms at 128 Mi)
-    // pass B when pass A has raised the overflow flag (final by now): every workgroup leaves, the net sorts (net_sort)
-    if (a.which_digit == 2 && __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const uint32_t chain = a.which_digit == 2 ? blockIdx.x / a.rows_per_chain : blockIdx.x % a.chains;
     // (pass B with a narrow second digit: the field sits 8 - w bits higher, see slot_to_segment)
     const int start_bit = (int)a.place->top - 8 * a.which_digit + (a.which_digit == 2 ? 8 - (int)a.seg_shift : 0);
 
     // ---- ticket -> tile index in the chain -> where the tile's elements are ------------------------------------------------
     if (w == 0) {
+        // pass B once the overflow flag is up (pass A's, or an earlier tile's of this pass): the net will sort (net_sort); wave 0
+        // decides for the workgroup -- no ticket, valid = 0, everybody leaves behind the barrier below
+        const bool give_up = a.which_digit == 2 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
         uint32_t index = 0u;
-        if (lane == 0) index = atomicAdd(&a.tickets[chain * (uint32_t)kTicketStride], 1u);
+        if (lane == 0 && !give_up) index = atomicAdd(&a.tickets[chain * (uint32_t)kTicketStride], 1u);
         index = (uint32_t)__builtin_amdgcn_readfirstlane((int)index);
         uint32_t base = 0u, valid = 0u;
-        if (a.which_digit == 1) {
+        if (give_up) {
+            // (nothing: valid stays 0)
+        } else if (a.which_digit == 1) {
             const uint32_t c0 = chain * a.slice;
             const uint32_t c1 = c0 + a.slice < a.n ? c0 + a.slice : a.n;
             const uint32_t off = index * (uint32_t)C::TILE;

@@ -137,8 +137,15 @@ __global__ __launch_bounds__(NT, WPE) void msd_scatter_persist_kernel(BucketPass
     // A run that did not fit its slab has raised the flag: the sort's result will come from the safety net (hybrid_kernels.hpp
     // net_sort), whatever is written from here on is never read.  The second pass leaves at once when the first has raised it; both
     // look at the flag once per tile (below) -- keys that are all equal overflow a slab within the first per cent of the input.
+    // Either way the decision is the same for every wave of the workgroup -- the flag can rise between two waves' loads, and a
+    // workgroup of which some waves have left would go on with stale counters and tickets: one thread's (one tile ago: every wave's)
+    // view goes through LDS and a barrier.
+    uint32_t* __restrict__ s_give = reinterpret_cast<uint32_t*>(smem + C::OFF_WSUM);   // [8 + 1] (the block scan's scratch: prologue only)
     if constexpr (PASS >= 2) {
-        if (__hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        if (tid == 0) s_give[8] = __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_give[8]) return;
+        __syncthreads();   // (the scan below reuses the scratch)
     }
     int start_bit = a.start_bit;
     Msd2Placement place{0, 0ull};
@@ -245,12 +252,14 @@ __global__ __launch_bounds__(NT, WPE) void msd_scatter_persist_kernel(BucketPass
     load_tile(tc, cur);
 #pragma unroll
     for (int j = 0; j < K; ++j) asm volatile("" : "+v"(cur[j]));
+    uint32_t flag_prev = 0u;   // the overflow flag as this wave loaded it during the previous tile
     for (;;) {
         const uint32_t ticket_n = ticket + t_step;
         const bool has_next = ticket_n < t_end;
-        // the overflow flag, requested with the next tile's keys and looked at where those are waited for (one more countable
-        // vector-memory operation in front of this tile's stores: the wait at the bottom stays s_waitcnt vmcnt(K))
-        const uint32_t give_up = __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the overflow flag, requested with the next tile's keys (one more countable vector-memory operation in front of this
+        // tile's stores: the wait at the bottom stays s_waitcnt vmcnt(K)) and looked at ONE TILE LATER, behind that tile's first
+        // barrier: by then it has long arrived, and every wave sees every wave's view
+        const uint32_t flag_now = __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (has_next) {
             tn = tile_of(ticket_n);
             load_tile(tn, nxt);   // in flight through the whole body below
@@ -299,7 +308,16 @@ __global__ __launch_bounds__(NT, WPE) void msd_scatter_persist_kernel(BucketPass
         }
 #pragma unroll
         for (int j = 0; j < (K + 1) / 2; ++j) asm volatile("" : "+v"(rnk2[j]));
+        if (lane == 0) s_give[w] = flag_prev;
         lds_barrier();
+        {   // leave together: nothing this workgroup writes from here on would be read
+            const u32x4 g0 = *reinterpret_cast<const u32x4*>(s_give), g1 = *reinterpret_cast<const u32x4*>(s_give + 4);
+            static_assert(NW <= 8, "one word per wave");
+            uint32_t any = 0u;
+            if (NW > 0) any |= g0.x; if (NW > 1) any |= g0.y; if (NW > 2) any |= g0.z; if (NW > 3) any |= g0.w;
+            if (NW > 4) any |= g1.x; if (NW > 5) any |= g1.y; if (NW > 6) any |= g1.z; if (NW > 7) any |= g1.w;
+            if (any) break;
+        }
         // ---- every wave: counts of all waves for its lanes' digits -> tile offsets -> its own (wave, digit) positions -------------
         u32x4 cnt4 = {0u, 0u, 0u, 0u};
         u32x4 toff4 = {0u, 0u, 0u, 0u};
@@ -400,7 +418,7 @@ __global__ __launch_bounds__(NT, WPE) void msd_scatter_persist_kernel(BucketPass
             }
         }
         if (!has_next) break;
-        if (give_up) break;   // (uniform: every lane loaded the same word)
+        flag_prev = flag_now;
         // (no barrier here: the next tile touches s_elems / s_goff / the positions only behind ITS first barrier, which every wave
         // reaches after its write-out; the wave's own counters are read by the other waves before this tile's second barrier)
         // the prefetched keys become the current ones: s_waitcnt vmcnt(K) -- the K stores above stay in flight
