@@ -329,8 +329,8 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      keys whose density varies by more than ~45 % over their range, or that repeat a few values, do not fit.
  *                      That is detected on the device -- the passes stop at their next tile -- and the sort's own offsets
  *                      kernel then sorts the untouched input: by counting if the keys take at most 256 values ("sort.dict"),
- *                      else by four (eight) LSD passes with grid-wide barriers between their phases (64 Mi u32 keys: 0.37 ms
- *                      and 1.4 ms instead of 0.32; profiles/r4_distributions.txt).  Nothing is reported to the host and
+ *                      else by four (eight) LSD passes with grid-wide barriers between them (64 Mi u32 keys: 0.37 ms
+ *                      and 1.1-1.2 ms instead of 0.32; profiles/r4_safety_net.txt).  Nothing is reported to the host and
  *                      nothing is remembered between sorts: a sort entry point never waits, and the first sort of an input
  *                      takes the time its hundredth does.  (Rounds 2-3 kept such keys off this path by a probe launch,
  *                      pinned-memory reports and a back-off counter in the handle; all of that is gone.)
@@ -341,6 +341,10 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *   "sort.dict"        1 [default] / 0: the large sort's safety net first samples 16 Ki keys; if they take at most 256 distinct
  *                      values (whole-key sorts of u32 / u64 keys only: equal keys are interchangeable) it sorts by counting
  *                      -- dictionary, one read, one write -- and falls through to its LSD passes when a key misses the dictionary
+ *   "sort.net_lookback" 1 [default] / 0: the LSD passes of the large sort's safety net on whole keys are look-back passes -- the
+ *                      one-sweep path's histogram, tables and tile body, taken in turns by the net's resident workgroups, four
+ *                      passes at a time (u64 keys: two rounds) -- instead of count -> scan -> scatter passes with per-workgroup
+ *                      carries (which sorts on part of the key and SoA arrays always get); same result, ~25 % less time
  *   "partition.lookback" 1 [default] / 0: adlhip_partition_* on 24 MiB of data and more, with a work buffer of the sort's
  *                      full-speed size, is one look-back pass (histogram + chain kernel of the one-sweep path) instead of
  *                      count -> scan -> scatter; the same output bit for bit

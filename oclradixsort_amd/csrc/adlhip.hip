@@ -96,6 +96,7 @@ struct adlhip_device {
                               // (1: u64 keys, 2: u32 keys too, 0: the wave-per-segment LSD finish)
     int persist = 1;          // "sort.persist": the cursor passes of the large sort as persistent, prefetching kernels + the 16-bit finish
     int msd2_path = 1;        // "sort.msd2": the large sort (msd2_sort for keys, msd2s_sort for pairs); 2 = forced (tests)
+    int net_lookback = 1;                   // "sort.net_lookback": the large sort's safety net runs look-back passes (0: count-scan-scatter passes)
     int partition_lookback = 1;             // "partition.lookback": the MSB partition as one look-back pass where it pays (0: always three kernels)
     int dict_path = 1;                      // "sort.dict": the large sort's safety net first tries the counting sort for keys that take at most
                                             // 256 values (dict_kernels.hpp); 0 = off
@@ -1053,6 +1054,37 @@ uint32_t net_wgs(const adlhip_device* d) { return d->resident_wgs >= (int)kNetWg
 // two handle-owned counters: nets run, and of those, sorted by counting (net_sort; "stat.net_runs" / "stat.net_counting")
 uint32_t* net_stats(const adlhip_device* d) { return d->d_msd2 + 8192 + 65536 + 16; }
 
+// Scratch of the net's look-back passes (hybrid_kernels.hpp coop_onesweep_sort), carved out of `region` -- the first slab area, whose
+// contents are void when the net runs.  tables == nullptr when it does not fit (small inputs) or the tile status words' 30-bit
+// counts would not do (n >= 2^30): the net then runs its count-scan-scatter passes.
+adlhip::OsNet net_onesweep_args(const adlhip_device* d, char* region, size_t region_bytes, size_t n, int passes, uint32_t tile)
+{
+    adlhip::OsNet os{};
+    if (!region || n >= (size_t(1) << 30) || n < (size_t(1) << 16) || !d->net_lookback) return os;
+    const uint32_t total_bins = (uint32_t)passes * ((uint32_t)adlhip::kChains << 8);
+    uint32_t hw = (uint32_t)std::min<size_t>(net_wgs(d), (n + adlhip::kHistChunk - 1) / adlhip::kHistChunk);
+    const uint32_t per_wg = (uint32_t)align_up((n + hw - 1) / hw, 1024);
+    const uint32_t wgs = (uint32_t)((n + per_wg - 1) / per_wg);
+    const uint32_t wgs_per_slice = (wgs + adlhip::kChains - 1) / adlhip::kChains;
+    const size_t rows = status_rows(n, tile);
+    const size_t off_tables = align_up((size_t)adlhip::kTicketVecs * 16, 256);
+    const size_t off_joint = align_up(off_tables + sizeof(adlhip::PassTable) * adlhip::kMaxPasses, 256);
+    const size_t off_part = align_up(off_joint + (size_t)total_bins * 4, 256);
+    const size_t off_status = align_up(off_part + (size_t)wgs * total_bins * 4, 256);
+    const size_t total = off_status + (size_t)passes * rows * 256 * 4;
+    if (total > region_bytes || (size_t)passes * rows * 256 * 4 >= (size_t(1) << 31)) return os;
+    os.ctrl = reinterpret_cast<adlhip::u32x4*>(region);
+    os.tables = reinterpret_cast<adlhip::PassTable*>(region + off_tables);
+    os.joint = reinterpret_cast<uint32_t*>(region + off_joint);
+    os.part = reinterpret_cast<uint32_t*>(region + off_part);
+    os.status = reinterpret_cast<uint32_t*>(region + off_status);
+    os.rows = (uint32_t)rows;
+    os.hist_wgs = wgs;
+    os.per_wg = per_wg;
+    os.slice0 = per_wg * wgs_per_slice;
+    return os;
+}
+
 Msd2Layout msd2_layout(size_t n, size_t elem_bytes, int headroom_pct = kFullHeadroomPct)
 {
     Msd2Layout L;
@@ -1172,7 +1204,8 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int headr
     rc = launch(d, "msd2_offsets", [&] {
         hipLaunchKernelGGL(ko, dim3(net_wgs(d)), dim3(512), CC::LDS_BYTES, d->stream, cur_a, cur_b, flag, done, bar,
                            seg_cnt, seg_off, mode, (uint32_t)n, sample, data, tmp, ctable, d->d_fault, KEY_BITS,
-                           8u - L.seg_shift, d->dict_path ? d->d_dict : nullptr, net_stats(d));
+                           8u - L.seg_shift, d->dict_path ? d->d_dict : nullptr, net_stats(d),
+                           net_onesweep_args(d, wb + L.off_slab_a, (size_t)256 * L.stride_a * sizeof(E), n, 4, CC::TILE));
     });
     if (rc) return rc;
     // the finish sorts the bits below the second digit (the offsets kernel has published how many)
@@ -1505,17 +1538,21 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
     // whole-key sorts of keys: equal keys are interchangeable, the net may sort them by counting (dict_kernels.hpp)
     adlhip::DictBlock* net_dict = (k32 || KEY64) && whole && !soa_keys && d->dict_path ? d->d_dict : nullptr;
     using CC = adlhip::TileCfg<E, 8, 512, NK>;   // the safety net's tile (it runs in the offsets kernel when a run did not fit)
-    auto ko = adlhip::msd2s_offsets_kernel<E, CT::TILE, 512, NK>;
+    // the net's look-back passes: whole keys; SoA input (packed into the first slab area) and sorts on part of the key run its
+    // count-scan-scatter passes
+    constexpr int NP = KEY64 ? 8 : 4;   // key bytes: passes of the net's look-back sort (run four at a time)
+    auto ko = adlhip::msd2s_offsets_kernel<E, CT::TILE, 512, NK, 1, NP>;
     if constexpr (sizeof(E) == 8 && !KEY64) {
-        if (d->rank_mode == 0) ko = adlhip::msd2s_offsets_kernel<E, CT::TILE, 512, NK, 0>;   // the net ranks by ballots too
+        if (d->rank_mode == 0) ko = adlhip::msd2s_offsets_kernel<E, CT::TILE, 512, NK, 0, NP>;   // the net ranks by ballots too
     }
     if (ensure_lds(ko, CC::LDS_BYTES)) return ADLHIP_FAILURE;
+    const adlhip::OsNet os = net_onesweep_args(d, (NP && whole && !soa_keys) ? wb + L.off_slab_a : nullptr, L.off_slab_b - L.off_slab_a, n, 4, CC::TILE);
     rc = launch(d, "msd2s_offsets", [&] {
         hipLaunchKernelGGL(ko, dim3(net_wgs(d)), dim3(512), CC::LDS_BYTES, d->stream,
                            (const uint32_t*)status_a, L.rows_a, L.slice, L.pieces, (const uint32_t*)status_b, L.rows_b, L.stride_a, flag,
                            done, bar, seg_cnt, seg_off, mode, (uint32_t)n, (const adlhip::StablePlace*)place,
                            soa_keys ? slab_a : data, soa_keys ? slab_b : tmp, ctable, d->d_fault, soa_keys, soa_vals, cur_b, 8u - L.seg_shift,
-                           net_dict, net_stats(d));
+                           net_dict, net_stats(d), os);
     });
     if (rc) return rc;
     const int low_max = sort_bits - 8 - (int)L.seg_shift;
@@ -1988,10 +2025,10 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         // workgroups each) this device keeps resident at once: asked of the runtime for the two largest of them
         int a = 0, b = 0;
         using CS = adlhip::TileCfg<uint32_t, 8, 512, 32>;
-        using CO = adlhip::TileCfg<uint64_t, 8, 512, 16>;
+        using CO = adlhip::TileCfg<uint32_t, 8, 512, 32>;
         const size_t lds_s = std::max<size_t>(sizeof(uint32_t) * 512 * 32 + (size_t)8 * 256 * 6 + 64, CS::LDS_BYTES);
         auto ks = adlhip::segment_sort_kernel<uint32_t, 512, 32, 8>;
-        auto ko = adlhip::msd2_offsets_kernel<uint64_t, 512, 16>;
+        auto ko = adlhip::msd2_offsets_kernel<uint32_t, 512, 32>;   // (the instantiation with the most static LDS: the net's look-back passes)
         if (ensure_lds(ks, lds_s) == ADLHIP_SUCCESS && ensure_lds(ko, CO::LDS_BYTES) == ADLHIP_SUCCESS &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(ks), 512, lds_s) == hipSuccess &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(ko), 512, CO::LDS_BYTES) == hipSuccess)
@@ -2514,6 +2551,8 @@ int adlhip_set_param(adlhip_device* d, const char* name, int value)
     } else if (!strcmp(name, "sort.persist")) {
         if (value != 0 && value != 1) return fail("sort.persist must be 0 (one tile per workgroup, round 3) or 1 (persistent prefetching passes + 16-bit finish)");
         d->persist = value;
+    } else if (!strcmp(name, "sort.net_lookback")) {
+        d->net_lookback = value ? 1 : 0;
     } else if (!strcmp(name, "partition.lookback")) {
         d->partition_lookback = value ? 1 : 0;
     } else if (!strcmp(name, "sort.dict")) {
@@ -2554,6 +2593,7 @@ int adlhip_get_param(adlhip_device* d, const char* name, int* value)
     else if (!strcmp(name, "sort.persist")) *value = d->persist;
     else if (!strcmp(name, "sort.dict")) *value = d->dict_path;
     else if (!strcmp(name, "partition.lookback")) *value = d->partition_lookback;
+    else if (!strcmp(name, "sort.net_lookback")) *value = d->net_lookback;
     else if (!strcmp(name, "debug.resident_wgs")) *value = d->resident_wgs;
     else if (!strcmp(name, "stat.net_runs") || !strcmp(name, "stat.net_counting")) {
         // how often the large sort's safety net has run on this handle, and how often it sorted by counting (waits for the stream)

@@ -219,14 +219,88 @@ __device__ __forceinline__ void coop_lsd_sort(E* data, E* tmp, uint32_t n, uint3
     }
 }
 
+// Scratch of the net's look-back passes (coop_onesweep_sort), carved by the host out of the first slab area -- void by the time the
+// net runs.  tables == nullptr: none (sorts on part of the key, tiny or huge inputs): the net then runs coop_lsd_sort.
+struct OsNet {
+    u32x4* ctrl;             // chain tickets of all passes (kTicketVecs vectors)
+    PassTable* tables;       // [passes]
+    uint32_t* joint;         // joint histograms of all passes
+    uint32_t* part;          // [hist_wgs][total_bins] partial histograms
+    uint32_t* status;        // [passes][rows][256] tile status words
+    uint32_t rows;           // status rows of one pass
+    uint32_t hist_wgs, per_wg, slice0;
+};
+
+// The net's LSD passes as the one-sweep path runs them (onesweep_kernels.hpp), inside ONE kernel: the resident workgroups take the
+// histogram workgroups, then the tiles of every pass, in turns; grid barriers stand where the kernel boundaries were.  Every key
+// is read once for all histograms and once per pass -- coop_lsd_sort reads it twice per pass and pays three barriers per pass
+// (64 Mi u32 keys: ~0.7 ms against 1.1).  P whole 8-bit passes (P even: the result ends in `data`).
+// base_bit: the passes sort bits [base_bit, base_bit + 8 P) -- u64 keys take two rounds of four passes (an LSD sort with two
+// 32-bit digits, each round stable), because the joint histograms of eight passes do not fit the tile's LDS.
+template <typename E, int NT, int K, int P, int RANK>
+__device__ __forceinline__ bool coop_onesweep_sort(E* data, E* tmp, uint32_t n, const OsNet& os, uint32_t* bar, uint32_t& target,
+                                                   uint32_t* fault, unsigned char* smem, int base_bit = 0)
+{
+    static_assert(P % 2 == 0, "an even number of passes ends in the caller's array");
+    using C = TileCfg<E, 8, NT, K>;
+    const uint32_t wgs = gridDim.x;
+    PassDesc desc;
+    desc.num_passes = P;
+#pragma unroll
+    for (int p = 0; p < kMaxPasses; ++p) {
+        desc.start_bit[p] = (uint8_t)(p < P ? base_bit + 8 * p : 0);
+        desc.nbits[p] = (uint8_t)(p < P ? 8 : 0);
+    }
+    constexpr uint32_t total_bins = (uint32_t)P * ((uint32_t)kChains << 8);
+    const uint32_t status_bytes = os.rows * 256u * 4u;
+    const size_t status_vecs = (size_t)P * os.rows * 256u * 4u / 16u;
+    // ---- joint histograms of all passes (and: tickets and status rows zeroed) --------------------------------------------
+    for (uint32_t v = blockIdx.x; v < os.hist_wgs; v += wgs) {
+        onesweep_hist_body<E, P, NT>(data, os.part, n, os.per_wg, os.slice0, desc, total_bins, os.ctrl, reinterpret_cast<u32x4*>(os.status),
+                                     status_vecs, fault, v, os.hist_wgs, smem);
+        __syncthreads();
+    }
+    if (!grid_barrier(bar, target, wgs, fault)) return false;
+    for (uint32_t v = blockIdx.x; v < (total_bins + 255u) / 256u; v += wgs)
+        onesweep_hist_reduce_body<NT>(os.part, os.joint, os.hist_wgs, total_bins, v);
+    if (!grid_barrier(bar, target, wgs, fault)) return false;
+    for (uint32_t v = blockIdx.x; v < (uint32_t)P; v += wgs) onesweep_tables_body<NT>(os.joint, os.tables, desc, (uint32_t)C::TILE, (int)v);
+    if (!grid_barrier(bar, target, wgs, fault)) return false;
+    // a pass whose digit is the same for every key moves nothing: skipped -- except that the number of passes run must stay even
+    // (the result belongs in `data`): one constant pass, a plain stable copy, runs then
+    uint32_t run_mask = 0u, constant_mask = 0u;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (os.tables[p].pad[0]) constant_mask |= 1u << p;
+        else run_mask |= 1u << p;
+    }
+    if (__builtin_popcount(run_mask) & 1) run_mask |= constant_mask & (0u - constant_mask);   // (odd => some pass is constant: P is even)
+    // ---- the passes ---------------------------------------------------------------------------------------------------------
+    E* src = data;
+    E* dst = tmp;
+#pragma unroll 1
+    for (int p = 0; p < P; ++p) {
+        if (!((run_mask >> p) & 1u)) continue;
+        const AosIO<E> io{src, dst};
+        uint32_t* st = os.status + (size_t)p * os.rows * 256u;
+        uint32_t* tk = reinterpret_cast<uint32_t*>(os.ctrl) + (size_t)p * kChains * kTicketStride;
+        while (onesweep_tile<AosIO<E>, 8, NT, K, RANK>(io, os.tables + p, st, status_bytes, tk, fault, n, base_bit + 8 * p, blockIdx.x, smem)) {
+        }
+        if (!grid_barrier(bar, target, wgs, fault)) return false;
+        E* t = src; src = dst; dst = t;
+    }
+    return true;
+}
+
 // The large sort's safety net, run by the workgroups of its offsets kernel when a run did not fit its slab (the input is then
 // untouched: the passes write only slabs).  dict != nullptr (whole-key sorts of keys): first the counting sort of
 // dict_kernels.hpp -- sample, look up and count, fill -- and only if the keys take more than 256 values, or one of them missed the
 // dictionary, the LSD passes.  `bar` is zero on entry.  No launch of its own, no word for the host to read: the same input takes the
 // same time whether it is the handle's first sort or its hundredth.
-template <typename E, int NT, int K, int RANK = 1>
+template <typename E, int NT, int K, int RANK = 1, int P = 0>
 __device__ __forceinline__ void net_sort(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table, uint32_t* bar, uint32_t* fault,
-                                         unsigned char* smem, int key_bits, DictBlock* dict, uint32_t* stats, uint32_t target0 = 0u)
+                                         unsigned char* smem, int key_bits, DictBlock* dict, uint32_t* stats, const OsNet& os,
+                                         uint32_t target0 = 0u)
 {
     uint32_t target = target0;
     const uint32_t wgs = gridDim.x;
@@ -244,6 +318,14 @@ __device__ __forceinline__ void net_sort(E* data, E* tmp, uint32_t n, uint32_t* 
                 return;
             }
             __syncthreads();   // (the fill's LDS is the LSD sort's)
+        }
+    }
+    if constexpr (P > 0) {
+        if (os.tables && key_bits == 8 * P) {   // whole keys: the look-back passes, four at a time
+#pragma unroll 1
+            for (int base = 0; base < 8 * P; base += 32)
+                if (!coop_onesweep_sort<E, NT, K, 4, RANK>(data, tmp, n, os, bar, target, fault, smem, base)) return;
+            return;
         }
     }
     coop_lsd_sort<E, NT, K, RANK>(data, tmp, n, table, table + 256 * wgs, bar, fault, smem, key_bits, target);
@@ -1456,7 +1538,8 @@ __global__ __launch_bounds__(NT) void msd2_offsets_kernel(uint32_t* cursors_a, u
                                                           uint32_t* __restrict__ mode, uint32_t n,
                                                           uint32_t* sample, E* data, E* tmp, uint32_t* __restrict__ ctable,
                                                           uint32_t* fault, int key_bits, uint32_t d2_shift /* 8 - w, slot_to_segment */,
-                                                          DictBlock* dict /* the net's counting sort, or nullptr */, uint32_t* stats)
+                                                          DictBlock* dict /* the net's counting sort, or nullptr */, uint32_t* stats,
+                                                          OsNet os)
 {
     static_assert(NT >= 256, "one thread per digit");
     __shared__ uint32_t s_wsum[NT / 64 + 1];
@@ -1502,7 +1585,7 @@ __global__ __launch_bounds__(NT) void msd2_offsets_kernel(uint32_t* cursors_a, u
     }
     if (overflow) {   // `bar` is zero here: msd2_sample_kernel, the first launch of every sort, clears it
         __syncthreads();
-        net_sort<E, NT, K>(data, tmp, n, ctable, bar, fault, smem, key_bits, dict, stats);
+        net_sort<E, NT, K, 1, (int)sizeof(E)>(data, tmp, n, ctable, bar, fault, smem, key_bits, dict, stats, os);
     }
 }
 
@@ -1862,7 +1945,7 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
 // Between pass B and the finish: workgroup b turns bucket b's final counts (the last status row of chain b) into the
 // segments' sizes and output offsets; the last workgroup publishes the mode word.
 // As in the keys-only form, the safety net runs in this kernel when the overflow flag is set.
-template <typename E, int TILE, int NT, int K, int RANK = 1>
+template <typename E, int TILE, int NT, int K, int RANK = 1, int P = 0>
 __global__ __launch_bounds__(NT) void msd2s_offsets_kernel(const uint32_t* __restrict__ status_a, uint32_t rows_per_chain_a, uint32_t slice,
                                                             uint32_t pieces,
                                                             const uint32_t* __restrict__ status_b, uint32_t rows_per_chain_b,
@@ -1874,7 +1957,7 @@ __global__ __launch_bounds__(NT) void msd2s_offsets_kernel(const uint32_t* __res
                                                             uint32_t* soa_vals, uint32_t* cursors_b /* hybrid form, else nullptr */,
                                                             uint32_t d2_shift /* 8 - w (slot_to_segment); stable second pass: 0 */,
                                                             DictBlock* dict /* whole-key sorts of keys: the net's counting sort, else nullptr */,
-                                                            uint32_t* stats)
+                                                            uint32_t* stats, OsNet os)
 {
     static_assert(NT >= 256, "one thread per digit");
     __shared__ uint32_t s_wsum[NT / 64 + 1];
@@ -1940,7 +2023,7 @@ __global__ __launch_bounds__(NT) void msd2s_offsets_kernel(const uint32_t* __res
                 if (!grid_barrier(bar, target, gridDim.x, fault)) return;
             }
         }
-        net_sort<E, NT, K, RANK>(data, tmp, n, ctable, bar, fault, smem, (int)place->sort_bits, soa_keys ? nullptr : dict, stats, target);
+        net_sort<E, NT, K, RANK, P>(data, tmp, n, ctable, bar, fault, smem, (int)place->sort_bits, soa_keys ? nullptr : dict, stats, os, target);
         if constexpr (sizeof(E) == 8) {
             if (soa_keys) {   // the sort's last phase ends with a grid barrier: `data` is complete
                 for (size_t i = (size_t)blockIdx.x * NT + (size_t)t; i < n; i += (size_t)gridDim.x * NT) {

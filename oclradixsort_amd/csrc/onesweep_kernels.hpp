@@ -105,32 +105,31 @@ __host__ __device__ inline uint32_t joint_bins(int nbits) { return (uint32_t)kCh
 // P (number of passes) is a template parameter so that the loop over passes unrolls with constant
 // indices: the pass descriptors then sit in SGPRs (indexed dynamically they were re-loaded from the
 // kernarg segment for every key).
-template <typename E, int P>
-__global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restrict__ src,
-                                                                uint32_t* __restrict__ partial, uint32_t n,
-                                                                uint32_t chunk, uint32_t slice0, PassDesc desc,
-                                                                uint32_t total_bins, u32x4* __restrict__ tickets,
-                                                                u32x4* __restrict__ status, size_t status_vecs,
-                                                                uint32_t* __restrict__ fault)
+// The body of one histogram workgroup, `vblock` of `vgrid`, run by NT threads: the kernel below (one workgroup each), or the large
+// sort's safety net (hybrid_kernels.hpp coop_onesweep_sort), whose resident workgroups take the histogram workgroups in turns.
+template <typename E, int P, int NT>
+__device__ __forceinline__ void onesweep_hist_body(const E* __restrict__ src, uint32_t* __restrict__ partial, uint32_t n, uint32_t chunk,
+                                                   uint32_t slice0, const PassDesc& desc, uint32_t total_bins,
+                                                   u32x4* __restrict__ tickets, u32x4* __restrict__ status, size_t status_vecs,
+                                                   uint32_t* __restrict__ fault, uint32_t vblock, uint32_t vgrid, unsigned char* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
     const int tid = (int)threadIdx.x;
     // Zero the chain tickets (1 KiB) and the status rows of all passes on the way: fire-and-forget stores that
     // drain under the key stream, instead of two memset launches in front of every sort.
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
-        if (blockIdx.x == 0) {
-            for (int i = tid; i < kTicketVecs; i += kHistNT) tickets[i] = z;
+        if (vblock == 0) {
+            for (int i = tid; i < kTicketVecs; i += NT) tickets[i] = z;
             if (tid == 0) fault[0] = 0u;   // the live fault word belongs to the sort that starts here
         }
-        const size_t stride = (size_t)gridDim.x * kHistNT;
-        for (size_t i = (size_t)blockIdx.x * kHistNT + (size_t)tid; i < status_vecs; i += stride) status[i] = z;
+        const size_t stride = (size_t)vgrid * NT;
+        for (size_t i = (size_t)vblock * NT + (size_t)tid; i < status_vecs; i += stride) status[i] = z;
     }
-    for (uint32_t i = (uint32_t)tid; i < total_bins; i += kHistNT) hist[i] = 0u;
+    for (uint32_t i = (uint32_t)tid; i < total_bins; i += NT) hist[i] = 0u;
     __syncthreads();
 
-    const uint64_t begin64 = (uint64_t)blockIdx.x * chunk;
+    const uint64_t begin64 = (uint64_t)vblock * chunk;
     if (begin64 < n) {
         const uint32_t begin = (uint32_t)begin64;
         const uint32_t end = (uint32_t)((begin64 + chunk < n) ? begin64 + chunk : n);
@@ -245,45 +244,71 @@ __global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restr
         const Vec* vsrc = reinterpret_cast<const Vec*>(src + begin);
         uint32_t i = (uint32_t)tid;
         // software-pipelined: the next four vectors are in flight while the current four are histogrammed
-        if (i + 3u * kHistNT < nvec) {
-            Vec a = vsrc[i], b = vsrc[i + kHistNT], c = vsrc[i + 2 * kHistNT], d4 = vsrc[i + 3 * kHistNT];
-            i += 4u * kHistNT;
-            for (; i + 3u * kHistNT < nvec; i += 4u * kHistNT) {
-                const Vec na = vsrc[i], nb = vsrc[i + kHistNT], nc = vsrc[i + 2 * kHistNT], nd = vsrc[i + 3 * kHistNT];
+        if (i + 3u * NT < nvec) {
+            Vec a = vsrc[i], b = vsrc[i + NT], c = vsrc[i + 2 * NT], d4 = vsrc[i + 3 * NT];
+            i += 4u * NT;
+            for (; i + 3u * NT < nvec; i += 4u * NT) {
+                const Vec na = vsrc[i], nb = vsrc[i + NT], nc = vsrc[i + 2 * NT], nd = vsrc[i + 3 * NT];
                 bump4(a, b, c, d4);
                 a = na; b = nb; c = nc; d4 = nd;
             }
             bump4(a, b, c, d4);
         }
-        for (; i < nvec; i += kHistNT) {
+        for (; i < nvec; i += NT) {
             Vec a = vsrc[i];
 #pragma unroll
             for (int k = 0; k < VEC; ++k) bump(a.v[k]);
         }
-        for (uint32_t s = begin + nvec * VEC + (uint32_t)tid; s < end; s += kHistNT) bump(src[s]);
+        for (uint32_t s = begin + nvec * VEC + (uint32_t)tid; s < end; s += NT) bump(src[s]);
     }
     __syncthreads();
-    uint32_t* out = partial + (size_t)blockIdx.x * total_bins;
-    for (uint32_t i = (uint32_t)tid; i < total_bins; i += kHistNT) out[i] = hist[i];
+    uint32_t* out = partial + (size_t)vblock * total_bins;
+    for (uint32_t i = (uint32_t)tid; i < total_bins; i += NT) out[i] = hist[i];
+}
+
+template <typename E, int P>
+__global__ __launch_bounds__(kHistNT) void onesweep_hist_kernel(const E* __restrict__ src,
+                                                                uint32_t* __restrict__ partial, uint32_t n,
+                                                                uint32_t chunk, uint32_t slice0, PassDesc desc,
+                                                                uint32_t total_bins, u32x4* __restrict__ tickets,
+                                                                u32x4* __restrict__ status, size_t status_vecs,
+                                                                uint32_t* __restrict__ fault)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    onesweep_hist_body<E, P, kHistNT>(src, partial, n, chunk, slice0, desc, total_bins, tickets, status, status_vecs, fault, blockIdx.x,
+                                      gridDim.x, smem);
 }
 
 // Sum the partial joint histograms over workgroups: joint[bin], all passes (grid = ceil(total_bins/256)).
-__global__ __launch_bounds__(1024) void onesweep_hist_reduce_kernel(const uint32_t* __restrict__ partial,
-                                                                    uint32_t* __restrict__ joint, uint32_t n_wgs,
-                                                                    uint32_t total_bins)
+template <int NT>
+__device__ __forceinline__ void onesweep_hist_reduce_body(const uint32_t* __restrict__ partial, uint32_t* __restrict__ joint, uint32_t n_wgs,
+                                                          uint32_t total_bins, uint32_t vblock)
 {
-    __shared__ uint32_t red[4][256];
+    constexpr int G = NT / 256;   // groups of 256 threads, each sums every G-th workgroup's partials
+    __shared__ uint32_t red[G][256];
     const int tid = (int)threadIdx.x;
-    const uint32_t bin = blockIdx.x * 256u + (uint32_t)(tid & 255);
+    const uint32_t bin = vblock * 256u + (uint32_t)(tid & 255);
     const int g = tid >> 8;
     uint32_t s = 0u;
     if (bin < total_bins) {
 #pragma unroll 8
-        for (uint32_t wg = (uint32_t)g; wg < n_wgs; wg += 4u) s += partial[(size_t)wg * total_bins + bin];
+        for (uint32_t wg = (uint32_t)g; wg < n_wgs; wg += (uint32_t)G) s += partial[(size_t)wg * total_bins + bin];
     }
     red[g][tid & 255] = s;
     __syncthreads();
-    if (tid < 256 && bin < total_bins) joint[bin] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < 256 && bin < total_bins) {
+        uint32_t t = 0u;
+#pragma unroll
+        for (int i = 0; i < G; ++i) t += red[i][tid];
+        joint[bin] = t;
+    }
+    __syncthreads();   // (red is written again by the caller's next block)
+}
+__global__ __launch_bounds__(1024) void onesweep_hist_reduce_kernel(const uint32_t* __restrict__ partial,
+                                                                    uint32_t* __restrict__ joint, uint32_t n_wgs,
+                                                                    uint32_t total_bins)
+{
+    onesweep_hist_reduce_body<1024>(partial, joint, n_wgs, total_bins, blockIdx.x);
 }
 
 // One workgroup (256 threads) per pass: joint histogram -> PassTable.
@@ -293,13 +318,12 @@ __global__ __launch_bounds__(1024) void onesweep_hist_reduce_kernel(const uint32
 //                    elements whose pass p-1 digit has a top nibble < c, i.e. where they start in the
 //                    array pass p-1 produced)
 //   tile_start[c]  = sum_{c' < c} ceil(len_c' / tile)
-__global__ __launch_bounds__(256) void onesweep_tables_kernel(const uint32_t* __restrict__ joint,
-                                                              PassTable* __restrict__ tables, PassDesc desc,
-                                                              uint32_t tile)
+template <int NT>
+__device__ __forceinline__ void onesweep_tables_body(const uint32_t* __restrict__ joint, PassTable* __restrict__ tables, const PassDesc& desc,
+                                                     uint32_t tile, int p)
 {
-    __shared__ uint32_t wsum[256 / 64 + 1];
-    __shared__ uint32_t rowpart[256 / 64][kChains];   // per wave: partial chain lengths
-    const int p = (int)blockIdx.x;
+    __shared__ uint32_t wsum[NT / 64 + 1];
+    __shared__ uint32_t rowpart[NT / 64][kChains];   // per wave: partial chain lengths (threads beyond the bins contribute zeros)
     const int tid = (int)threadIdx.x;
     const int nb = desc.nbits[p];
     const uint32_t bins = 1u << nb;
@@ -322,7 +346,12 @@ __global__ __launch_bounds__(256) void onesweep_tables_kernel(const uint32_t* __
         const uint32_t r = wave_incl_scan_u32(col[c]);
         if ((tid & 63) == 63) rowpart[tid >> 6][c] = r;
     }
-    const uint32_t gb = block_excl_scan_u32<256>(tot, wsum, nullptr);   // two barriers: rowpart is visible after them
+    uint32_t total;
+    const uint32_t gb = block_excl_scan_u32<NT>(tot, wsum, &total);   // two barriers: rowpart is visible after them
+    {   // every element has the same digit here: the pass would move nothing (read by the safety net's passes, which then skip it)
+        const int constant = __syncthreads_or((uint32_t)tid < bins && tot == total && total != 0u);
+        if (tid == 0) T->pad[0] = constant ? 1u : 0u;
+    }
     uint32_t run = gb;
 #pragma unroll
     for (int c = 0; c < kChains; ++c) {
@@ -332,13 +361,22 @@ __global__ __launch_bounds__(256) void onesweep_tables_kernel(const uint32_t* __
     if (tid <= kChains) {   // thread c: where chain c starts (elements and tiles); thread kChains: the totals
         uint32_t es = 0u, ts = 0u;
         for (int c = 0; c < tid; ++c) {
-            const uint32_t len = rowpart[0][c] + rowpart[1][c] + rowpart[2][c] + rowpart[3][c];
+            uint32_t len = 0u;
+#pragma unroll
+            for (int wv = 0; wv < NT / 64; ++wv) len += rowpart[wv][c];
             es += len;
             ts += (len + tile - 1u) / tile;
         }
         T->chunk_start[tid] = es;   // [kChains] == n
         T->tile_start[tid] = ts;
     }
+    __syncthreads();   // (the scratch is written again by the caller's next pass)
+}
+__global__ __launch_bounds__(256) void onesweep_tables_kernel(const uint32_t* __restrict__ joint,
+                                                              PassTable* __restrict__ tables, PassDesc desc,
+                                                              uint32_t tile)
+{
+    onesweep_tables_body<256>(joint, tables, desc, tile, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -407,22 +445,23 @@ __device__ __forceinline__ u32x4 lookback_exclusive4(__amdgpu_buffer_rsrc_t rsrc
 //   wave 0 then: look-back over its chain, publish inclusive prefix, global offsets    | barrier C
 //   write-out: consecutive lanes store consecutive elements of a digit's run.
 // ------------------------------------------------------------------------------------------
+// One tile of a pass: takes a ticket (home chain `home`, then the others in turn), ranks, scatters, looks back, writes out.
+// Returns false -- for every thread of the workgroup alike -- when every chain is fully ticketed.  Called once per workgroup by
+// the kernel below, and in a loop by the resident workgroups of the large sort's safety net (hybrid_kernels.hpp
+// coop_onesweep_sort): a tile only ever waits for tiles whose tickets were taken before its own, i.e. for workgroups that are
+// already at work, so the loop cannot deadlock; LDS is reused safely because a wave reaches the next tile's second barrier only
+// after every wave has left this tile's write-out.
 template <typename IO, int NBITS, int NT, int K, int RANK>
-__global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTable* __restrict__ table, uint32_t* status,
-                                                            uint32_t status_bytes, uint32_t* tickets, uint32_t* fault,
-                                                            uint32_t n, int start_bit, const uint32_t* __restrict__ dyn_start_bit)
+__device__ __forceinline__ bool onesweep_tile(const IO& io, const PassTable* __restrict__ table, uint32_t* status, uint32_t status_bytes,
+                                              uint32_t* tickets, uint32_t* fault, uint32_t n, int start_bit, uint32_t home,
+                                              unsigned char* smem)
 {
     typedef typename IO::elem_t E;
     using C = TileCfg<E, NBITS, NT, K>;
-    if (dyn_start_bit) {   // the mid-size sort picks its digit position on the device (MidDyn: start_bit, low_bits, mode)
-        if (dyn_start_bit[2] != 0u) return;   // ... and may hand the input to its cooperative LSD kernel instead
-        start_bit = (int)dyn_start_bit[0];
-    }
     constexpr int BINS = C::BINS;
     constexpr int NW = C::NW;
     constexpr int BK_LANES = BINS / 4;   // bookkeeping lanes: 4 digits each
     static_assert(BK_LANES <= 64, "one wave keeps the books");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     E* __restrict__ s_elems = reinterpret_cast<E*>(smem + C::OFF_ELEMS);
     uint32_t* __restrict__ s_wcnt = reinterpret_cast<uint32_t*>(smem + C::OFF_WCNT);   // [NW][BINS]
     uint32_t* __restrict__ s_goff = reinterpret_cast<uint32_t*>(smem + C::OFF_GOFF);   // [BINS]
@@ -451,7 +490,7 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTab
     // breath -- speculatively: a ticket beyond the chain's tile count is simply void.  (Done one after the other
     // -- tile count, ticket, table words -- this preamble cost three dependent round trips per tile.)
     if (w == 0) {
-        const uint32_t c0 = blockIdx.x % (uint32_t)kChains;
+        const uint32_t c0 = home % (uint32_t)kChains;
         uint32_t v = 0u;
         if (lane <= kChains) v = table->tile_start[lane];
         else if (lane <= 2 * kChains + 1) v = table->chunk_start[lane - (kChains + 1)];
@@ -484,7 +523,7 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTab
     }
     __syncthreads();
     const uint32_t chain = s_misc[0];
-    if (chain == 0xffffffffu) return;   // every chain is fully ticketed (the grid is an upper bound on the tile count)
+    if (chain == 0xffffffffu) return false;   // every chain is fully ticketed (the grid is an upper bound on the tile count)
     const uint32_t index = s_misc[1];
     const uint32_t first_row = s_misc[2];
     const uint32_t tile = first_row + index;                  // status row of this tile
@@ -629,6 +668,20 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTab
         g_stamp_buf[(size_t)tile * 16 + 14] = rt;
     }
 #endif
+    return true;
+}
+
+template <typename IO, int NBITS, int NT, int K, int RANK>
+__global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTable* __restrict__ table, uint32_t* status,
+                                                            uint32_t status_bytes, uint32_t* tickets, uint32_t* fault,
+                                                            uint32_t n, int start_bit, const uint32_t* __restrict__ dyn_start_bit)
+{
+    if (dyn_start_bit) {   // the mid-size sort picks its digit position on the device (MidDyn: start_bit, low_bits, mode)
+        if (dyn_start_bit[2] != 0u) return;   // ... and may hand the input to its cooperative LSD kernel instead
+        start_bit = (int)dyn_start_bit[0];
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    onesweep_tile<IO, NBITS, NT, K, RANK>(io, table, status, status_bytes, tickets, fault, n, start_bit, blockIdx.x, smem);
 }
 
 // totals[d] = sum over the 16 chains of pass 0's joint histogram (chain-major: joint[chain * 256 + digit]; 8-bit digits)

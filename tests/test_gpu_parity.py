@@ -2185,3 +2185,36 @@ def test_rank0_pairs_take_the_stable_large_sort(dev):
         dev.setParam("sort.msd2", 1)
         set_algo(dev, (-1, 8, -1))
         p.close()
+
+
+def test_net_passes_by_lookback_and_by_count_scan_scatter_agree(dev):
+    """The safety net's LSD passes exist twice: look-back passes (the one-sweep path's histogram, tables and tile body, taken in
+    turns by the net's resident workgroups; "sort.net_lookback" = 1, the default for whole keys) and count -> scan -> scatter passes
+    with per-workgroup carries (0; also what sorts on part of the key and SoA arrays get).  Skewed u32 keys, u64 keys and pairs
+    through both, bit-exact against the oracle; keys with constant bytes (passes skipped, an odd number left to run) too."""
+    p = Pprims()
+    n = (1 << 22) + 4321
+    u = oracle.keys_u32(n, seed=41)
+    heavy = np.where(np.arange(n) % 10 != 0, (u >> np.uint32(8)) | np.uint32(0x37000000), u).astype(np.uint32)
+    odd = (heavy & np.uint32(0x00ffffff)) | np.uint32(0x5a000000)                      # constant top byte: three passes vary
+    k64 = (heavy.astype(np.uint64) << np.uint64(32)) | u.astype(np.uint64)
+    k64c = (heavy.astype(np.uint64) << np.uint64(24)) | np.uint64(0x7700000000000000)   # constant bytes in both 32-bit halves
+    pairs = heavy.astype(np.uint64) | (np.arange(n, dtype=np.uint64) << np.uint64(32))
+    pairs_few = (u % np.uint32(1000)).astype(np.uint64) * np.uint64(0x10001) | (np.arange(n, dtype=np.uint64) << np.uint64(32))
+    try:
+        dev.setParam("sort.msd2", 2)
+        for lookback in (1, 0):
+            dev.setParam("sort.net_lookback", lookback)
+            runs = dev.getParam("stat.net_runs")
+            assert np.array_equal(gpu_sort_u32(dev, p, heavy), oracle.sort_u32(heavy)), lookback
+            assert np.array_equal(gpu_sort_u32(dev, p, odd), oracle.sort_u32(odd)), lookback
+            assert np.array_equal(gpu_sort_u64(dev, p, k64), oracle.sort_u64(k64)), lookback
+            assert np.array_equal(gpu_sort_u64(dev, p, k64c), oracle.sort_u64(k64c)), lookback
+            assert np.array_equal(gpu_sort_kv(dev, p, pairs), oracle.sort_kv32(pairs)), lookback
+            assert np.array_equal(gpu_sort_kv(dev, p, pairs_few), oracle.sort_kv32(pairs_few)), lookback
+            assert dev.getParam("stat.net_runs") == runs + 6, lookback
+        dev.checkFault()
+    finally:
+        dev.setParam("sort.net_lookback", 1)
+        dev.setParam("sort.msd2", 1)
+        p.close()
