@@ -25,6 +25,17 @@
 #include "finish16_kernels.hpp"
 #include "soa_wide_kernels.hpp"
 
+// The large sort's kernels and the per-digit passes' are instantiated in kernels_finish.hip / kernels_passes.hip / kernels_perdigit.hip (translation units of
+// their own, compiled beside this one); here they are only declared.  -DADLHIP_SINGLE_TU builds everything in this file (what tools/gen_large_kernels.py reads the list from).
+#ifndef ADLHIP_SINGLE_TU
+#define X(...) extern template __global__ __VA_ARGS__;
+#include "finish_kernels.inc"
+#include "wavefinish_kernels.inc"
+#include "passes_kernels.inc"
+#include "perdigit_kernels.inc"
+#undef X
+#endif
+
 namespace {
 
 thread_local char g_err[512] = "";

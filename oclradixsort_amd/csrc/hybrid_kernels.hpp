@@ -1204,7 +1204,7 @@ __device__ __forceinline__ size_t probe_sample_index(uint32_t k, uint32_t n)
     return (size_t)at;
 }
 // self-test: out[0] = the largest position any of the 16384 samples reads for this n, out[1] = positions outside their cell
-__global__ __launch_bounds__(1024) void probe_positions_selftest_kernel(uint32_t n, uint32_t* __restrict__ out)
+ADLHIP_KERNEL __global__ __launch_bounds__(1024) void probe_positions_selftest_kernel(uint32_t n, uint32_t* __restrict__ out)
 {
     uint32_t hi = 0u, bad = 0u;
     for (int i = 0; i < 16; ++i) {

@@ -304,7 +304,7 @@ __device__ __forceinline__ void onesweep_hist_reduce_body(const uint32_t* __rest
     }
     __syncthreads();   // (red is written again by the caller's next block)
 }
-__global__ __launch_bounds__(1024) void onesweep_hist_reduce_kernel(const uint32_t* __restrict__ partial,
+ADLHIP_KERNEL __global__ __launch_bounds__(1024) void onesweep_hist_reduce_kernel(const uint32_t* __restrict__ partial,
                                                                     uint32_t* __restrict__ joint, uint32_t n_wgs,
                                                                     uint32_t total_bins)
 {
@@ -372,7 +372,7 @@ __device__ __forceinline__ void onesweep_tables_body(const uint32_t* __restrict_
     }
     __syncthreads();   // (the scratch is written again by the caller's next pass)
 }
-__global__ __launch_bounds__(256) void onesweep_tables_kernel(const uint32_t* __restrict__ joint,
+ADLHIP_KERNEL __global__ __launch_bounds__(256) void onesweep_tables_kernel(const uint32_t* __restrict__ joint,
                                                               PassTable* __restrict__ tables, PassDesc desc,
                                                               uint32_t tile)
 {
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(NT) void onesweep_chain_kernel(IO io, const PassTab
 }
 
 // totals[d] = sum over the 16 chains of pass 0's joint histogram (chain-major: joint[chain * 256 + digit]; 8-bit digits)
-__global__ __launch_bounds__(256) void fold_joint_kernel(const uint32_t* __restrict__ joint, uint32_t* __restrict__ totals)
+ADLHIP_KERNEL __global__ __launch_bounds__(256) void fold_joint_kernel(const uint32_t* __restrict__ joint, uint32_t* __restrict__ totals)
 {
     uint32_t s = 0u;
 #pragma unroll
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) void fold_joint_kernel(const uint32_t* __restr
 }
 
 // counts[k] = number of keys whose top log2(num_buckets) bits equal k, from the 256 top-byte totals.
-__global__ __launch_bounds__(256) void fold_buckets_kernel(const uint32_t* __restrict__ totals,
+ADLHIP_KERNEL __global__ __launch_bounds__(256) void fold_buckets_kernel(const uint32_t* __restrict__ totals,
                                                            uint32_t* __restrict__ counts, int num_buckets)
 {
     __shared__ uint32_t t[256];

@@ -15,6 +15,11 @@
 // the in-tile ranking is a 64-lane ballot match (no packed counters, no LDS scans), the digit
 // width is a template parameter (8 bits by default, 4 = the reference's), tiles are 4-16 K keys.
 #pragma once
+// non-template kernels: external linkage in the translation unit that launches them (adlhip.hip), internal (and so dropped, unused)
+// in the one that only instantiates kernel templates (kernels_large.hip)
+#ifndef ADLHIP_KERNEL
+#define ADLHIP_KERNEL
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -916,7 +921,7 @@ __device__ __forceinline__ uint32_t scan_tile(const uint32_t* __restrict__ src, 
 }
 
 // Block sums: partial[block] = sum of the block's tile.
-__global__ __launch_bounds__(kScanNT) void scan_reduce_kernel(const uint32_t* __restrict__ src,
+ADLHIP_KERNEL __global__ __launch_bounds__(kScanNT) void scan_reduce_kernel(const uint32_t* __restrict__ src,
                                                               uint32_t* __restrict__ partial, size_t n)
 {
     __shared__ uint32_t wsum[kScanNT / 64];
@@ -947,7 +952,7 @@ __global__ __launch_bounds__(kScanNT) void scan_reduce_kernel(const uint32_t* __
 // Single workgroup: exclusive scan of data[0..count) in place (tile loop with carry); the grand total
 // goes to data[count] (the reference writes it to the same slot, PrefixScanKernels.cl:139-142).
 // With src != data it is the whole scan for small n.
-__global__ __launch_bounds__(kScanNT) void scan_single_kernel(const uint32_t* __restrict__ src,
+ADLHIP_KERNEL __global__ __launch_bounds__(kScanNT) void scan_single_kernel(const uint32_t* __restrict__ src,
                                                               uint32_t* __restrict__ dst, size_t count,
                                                               uint32_t* __restrict__ total_out)
 {
@@ -960,7 +965,7 @@ __global__ __launch_bounds__(kScanNT) void scan_single_kernel(const uint32_t* __
 
 // Block b rescans its tile with the scanned block sum as carry-in
 // (LocalScan + AddOffset of the reference fused: one read, one write).
-__global__ __launch_bounds__(kScanNT) void scan_apply_kernel(const uint32_t* __restrict__ src,
+ADLHIP_KERNEL __global__ __launch_bounds__(kScanNT) void scan_apply_kernel(const uint32_t* __restrict__ src,
                                                              uint32_t* __restrict__ dst,
                                                              const uint32_t* __restrict__ partial_ex, size_t n)
 {
@@ -972,7 +977,7 @@ __global__ __launch_bounds__(kScanNT) void scan_apply_kernel(const uint32_t* __r
 // ------------------------------------------------------------------------------------------
 // bandwidth probes + fill
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void probe_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src,
+ADLHIP_KERNEL __global__ __launch_bounds__(256) void probe_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src,
                                                          size_t nvec)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1022,7 +1027,7 @@ __global__ __launch_bounds__(256) void probe_read_hint_kernel(const uint4* __res
     if (acc == 0x9e3779b9u) atomicAdd(sink, 1ull);   // practically never; keeps the loads alive
 }
 
-__global__ __launch_bounds__(256) void probe_read_kernel(const uint4* __restrict__ src, size_t nvec,
+ADLHIP_KERNEL __global__ __launch_bounds__(256) void probe_read_kernel(const uint4* __restrict__ src, size_t nvec,
                                                          unsigned long long* __restrict__ sink)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1036,7 +1041,7 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const uint4* __restrict
     if (acc == 0x9e3779b9u) atomicAdd(sink, 1ull);   // practically never; keeps the loads alive
 }
 
-__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ dst, uint32_t pattern, size_t count)
+ADLHIP_KERNEL __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ dst, uint32_t pattern, size_t count)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[i] = pattern;
@@ -1044,7 +1049,7 @@ __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ ds
 
 // count copies of a 16-byte pattern (8-byte patterns are doubled by the host: count is then in 16-byte units
 // plus an optional 8-byte tail written by thread 0)
-__global__ __launch_bounds__(256) void fill_pattern16_kernel(uint4* __restrict__ dst, uint4 pattern, size_t count,
+ADLHIP_KERNEL __global__ __launch_bounds__(256) void fill_pattern16_kernel(uint4* __restrict__ dst, uint4 pattern, size_t count,
                                                              uint2* __restrict__ tail8, uint2 tail_pattern)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1059,7 +1064,7 @@ __global__ __launch_bounds__(256) void fill_pattern16_kernel(uint4* __restrict__
 // its own counters, so the LDS unit is contended the way it is in a pass), sixteen atomics back to back per lane,
 // and rounds with a pseudo-random subset of the lanes switched off (partial waves: tail tiles, segment ends).
 // It also runs on its own stream beside real sorts (adlhip_selftest_lds_order; tests/test_gpu_parity.py).
-__global__ __launch_bounds__(1024) void lds_order_selftest_kernel(uint32_t* __restrict__ mismatches, uint32_t salt)
+ADLHIP_KERNEL __global__ __launch_bounds__(1024) void lds_order_selftest_kernel(uint32_t* __restrict__ mismatches, uint32_t salt)
 {
     __shared__ uint32_t c_atomic[16][256];
     __shared__ uint32_t c_ballot[16][256];
@@ -1109,7 +1114,7 @@ __device__ __forceinline__ uint64_t splitmix64_at(uint64_t x)
 }
 
 // kind: 0 = u32 keys, 1 = {key32, index} pairs, 2 = u64 keys
-__global__ __launch_bounds__(256) void generate_keys_kernel(void* __restrict__ dst, size_t n, uint64_t base,
+ADLHIP_KERNEL __global__ __launch_bounds__(256) void generate_keys_kernel(void* __restrict__ dst, size_t n, uint64_t base,
                                                             uint64_t first_index, int kind)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
