@@ -327,10 +327,13 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      are indistinguishable), from 192 Mi u32 / 48 Mi u64 keys the first (or both) passes by look-back;
  *                      pairs and sorts on part of the key: by look-back, stably.  The slabs give every bucket the same room:
  *                      keys whose density varies by more than ~45 % over their range, or that repeat a few values, do not fit.
- *                      That is detected on the device -- the passes stop at their next tile -- and the sort's own offsets
- *                      kernel then sorts the untouched input: by counting if the keys take at most 256 values ("sort.dict"),
- *                      else by four (eight) LSD passes with grid-wide barriers between them (64 Mi u32 keys: 0.37 ms
- *                      and 1.1-1.2 ms instead of 0.32; profiles/r4_safety_net.txt).  Nothing is reported to the host and
+ *                      That is detected on the device -- by the sort's first kernel when its 2048 sampled keys repeat
+ *                      themselves (the passes then leave at once), else by the passes, which stop at their next tile -- and
+ *                      the sort's own offsets kernel then sorts the untouched input: keys that take at most 256 values by
+ *                      counting, pairs with such keys by one stable pass on the key's rank among them ("sort.dict"), anything
+ *                      else by four (eight) LSD passes with grid-wide barriers between them (64 Mi u32 keys: 0.30-0.44 ms
+ *                      and 1.0-1.1 ms instead of 0.32; 64 Mi pairs: 0.6-0.75 and 1.4-1.5 instead of 0.75;
+ *                      profiles/r4_safety_net.txt).  Nothing is reported to the host and
  *                      nothing is remembered between sorts: a sort entry point never waits, and the first sort of an input
  *                      takes the time its hundredth does.  (Rounds 2-3 kept such keys off this path by a probe launch,
  *                      pinned-memory reports and a back-off counter in the handle; all of that is gone.)
@@ -338,9 +341,11 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *   "sort.binfinish"   1 [default]: whole u64 keys finish their segments by one counting pass on the top bits below the
  *                      digits + whole-key compares inside the bins (where a segment holds ~384 keys and more); 0: the
  *                      wave-per-segment LSD finish; 2: always, u32 keys too (tests, measurements)
- *   "sort.dict"        1 [default] / 0: the large sort's safety net first samples 16 Ki keys; if they take at most 256 distinct
- *                      values (whole-key sorts of u32 / u64 keys only: equal keys are interchangeable) it sorts by counting
- *                      -- dictionary, one read, one write -- and falls through to its LSD passes when a key misses the dictionary
+ *   "sort.dict"        1 [default] / 0: the large sort's safety net first samples 16 Ki keys (if the sort's first kernel saw its
+ *                      samples repeat often enough for that to be possible); if they take at most 256 distinct values
+ *                      (whole-key sorts only) it sorts u32 / u64 keys by counting -- dictionary, one read, one write: equal
+ *                      keys are interchangeable -- and {key, value} pairs by ONE stable pass on the key's rank in the
+ *                      dictionary; it falls through to its LSD passes when a key misses the dictionary
  *   "sort.net_lookback" 1 [default] / 0: the LSD passes of the large sort's safety net on whole keys are look-back passes -- the
  *                      one-sweep path's histogram, tables and tile body, taken in turns by the net's resident workgroups, four
  *                      passes at a time (u64 keys: two rounds) -- instead of count -> scan -> scatter passes with per-workgroup

@@ -1063,7 +1063,21 @@ constexpr uint32_t kNetWgsMax = 512;
 constexpr size_t kNetTableBytes = (size_t)256 * kNetWgsMax * 4 + 1024;   // [256][workgroups] digit table + 256 totals
 uint32_t net_wgs(const adlhip_device* d) { return d->resident_wgs >= (int)kNetWgsMax ? kNetWgsMax : 256u; }
 // two handle-owned counters: nets run, and of those, sorted by counting (net_sort; "stat.net_runs" / "stat.net_counting")
+// d_msd2: 256 first-pass cursors (one line each) + 65536 second-pass cursors + 64 words (flag, done, barrier, sample words, the
+// first kernel's repeat count and arrival word, net counters)
+constexpr size_t kMsd2Words = 8192 + 65536 + 64;
 uint32_t* net_stats(const adlhip_device* d) { return d->d_msd2 + 8192 + 65536 + 16; }
+
+// Repeats the sort's first kernel must count among its samples (hybrid_kernels.hpp sample_accumulate: 16 waves, each comparing
+// its own 128 samples) to call the keys too repetitive for the slabs: D distinct values, each with n / D copies, repeat
+// 16 (128 - D (1 - e^(-128/D))) times; taken at D = n / 3072 (twice what a segment slab of ~1500 holds), with 20 % off for the
+// sample's noise, never below 4 (keys without repeats show none: 3e-5 expected for random 32-bit keys).  At 64 Mi keys: 4, which
+// 4096 values exceed eight times over and 30 000 values (2000 copies each: no fit either) reach every other time.
+uint32_t sample_dup_threshold(size_t n)
+{
+    const double S = 128.0, D = std::max(1.0, (double)n / 3072.0);
+    return (uint32_t)std::max(4.0, 0.8 * 16.0 * (S - D * (1.0 - std::exp(-S / D))));
+}
 
 // Scratch of the net's look-back passes (hybrid_kernels.hpp coop_onesweep_sort), carved out of `region` -- the first slab area, whose
 // contents are void when the net runs.  tables == nullptr when it does not fit (small inputs) or the tile status words' 30-bit
@@ -1158,7 +1172,7 @@ int msd2_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int headr
     // 1024 strided keys are 1024 cache lines, twice a tile's own; pass 1 at 64 Mi keys 0.150 -> 0.166 ms, nothing gained at 4 Mi.)
     int rc = launch(d, "msd2_sample", [&] {
         hipLaunchKernelGGL(adlhip::msd2_sample_kernel<E>, dim3(adlhip::kSampleWGs), dim3(64), 0, d->stream, (const E*)data, (uint32_t)n,
-                           sample, flag + 2, d->d_fault);
+                           sample, flag + 2, d->d_fault, flag, sample_dup_threshold(n));
     });
     if (rc) return rc;
     adlhip::BucketPass<E> pa;   // pass 1: the input, first digit -> 256 bucket slabs
@@ -1491,13 +1505,14 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
     if (ensure_lds(kern, CT::LDS_BYTES)) return ADLHIP_FAILURE;
     // status rows of both passes: zero (one memset; the rows are contiguous).  Hybrid: pass A's only.
     HIPCHK(hipMemsetAsync(status_a, 0, hybrid ? L.status_bytes_a : (L.off_status_b - L.off_status_a) + L.status_bytes_b, d->stream));
+    const uint32_t dup_thr = sample_dup_threshold(n);
     int rc = launch(d, "msd2s_prep", [&] {
         if (soa_keys)
-            hipLaunchKernelGGL((adlhip::msd2s_prep_kernel<uint32_t, false>), dim3(1), dim3(1024), 0, d->stream, (const uint32_t*)soa_keys,
-                               (uint32_t)n, place, tickets, L.ticket_words, bar, d->d_fault, (uint32_t)sort_bits);
+            hipLaunchKernelGGL((adlhip::msd2s_prep_kernel<uint32_t, false>), dim3(adlhip::kSampleWGs), dim3(64), 0, d->stream, (const uint32_t*)soa_keys,
+                               (uint32_t)n, place, tickets, L.ticket_words, bar, d->d_fault, (uint32_t)sort_bits, flag, dup_thr);
         else
-            hipLaunchKernelGGL((adlhip::msd2s_prep_kernel<E, KEY64>), dim3(1), dim3(1024), 0, d->stream, (const E*)data, (uint32_t)n, place,
-                               tickets, L.ticket_words, bar, d->d_fault, (uint32_t)sort_bits);
+            hipLaunchKernelGGL((adlhip::msd2s_prep_kernel<E, KEY64>), dim3(adlhip::kSampleWGs), dim3(64), 0, d->stream, (const E*)data, (uint32_t)n, place,
+                               tickets, L.ticket_words, bar, d->d_fault, (uint32_t)sort_bits, flag, dup_thr);
     });
     if (rc) return rc;
     adlhip::LookbackPass<E> pa;
@@ -1546,8 +1561,9 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
     }
     uint32_t* ctable = reinterpret_cast<uint32_t*>(wb + L.off_coop);
     constexpr int NK = sizeof(E) == 4 ? 32 : 16;
-    // whole-key sorts of keys: equal keys are interchangeable, the net may sort them by counting (dict_kernels.hpp)
-    adlhip::DictBlock* net_dict = (k32 || KEY64) && whole && !soa_keys && d->dict_path ? d->d_dict : nullptr;
+    // whole-key sorts: keys of few values are sorted by counting (equal keys are interchangeable), pairs with such keys by ONE
+    // stable pass on the key's rank among the values (dict_kernels.hpp)
+    adlhip::DictBlock* net_dict = whole && !soa_keys && d->dict_path ? d->d_dict : nullptr;
     using CC = adlhip::TileCfg<E, 8, 512, NK>;   // the safety net's tile (it runs in the offsets kernel when a run did not fit)
     // the net's look-back passes: whole keys; SoA input (packed into the first slab area) and sorts on part of the key run its
     // count-scan-scatter passes
@@ -2002,8 +2018,8 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
     }
     // the large sort's handle-owned words (cursors, flags: 270 KB), zero between sorts -- allocated here rather than by a handle's
     // first large sort
-    if (hipMalloc(&d->d_msd2, (8192 + 65536 + 64) * 4) != hipSuccess ||
-        hipMemsetAsync(d->d_msd2, 0, (8192 + 65536 + 64) * 4, d->stream) != hipSuccess ||
+    if (hipMalloc(&d->d_msd2, kMsd2Words * 4) != hipSuccess ||
+        hipMemsetAsync(d->d_msd2, 0, kMsd2Words * 4, d->stream) != hipSuccess ||
         hipMemsetAsync(d->d_msd2 + 8192 + 65536 + 10, 0xff, 8, d->stream) != hipSuccess) {   // the sample's AND words: all ones when idle
         if (d->d_msd2) hipFree(d->d_msd2);
         hipFree(d->d_mid_hist);
@@ -2039,11 +2055,17 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         using CO = adlhip::TileCfg<uint32_t, 8, 512, 32>;
         const size_t lds_s = std::max<size_t>(sizeof(uint32_t) * 512 * 32 + (size_t)8 * 256 * 6 + 64, CS::LDS_BYTES);
         auto ks = adlhip::segment_sort_kernel<uint32_t, 512, 32, 8>;
-        auto ko = adlhip::msd2_offsets_kernel<uint32_t, 512, 32>;   // (the instantiation with the most static LDS: the net's look-back passes)
+        auto ko = adlhip::msd2_offsets_kernel<uint32_t, 512, 32>;   // (the net's look-back passes)
+        // (the most LDS of all: the pairs' tile + the dictionary values of coop_dict_pair_sort)
+        using CP = adlhip::TileCfg<uint64_t, 8, 512, 16>;
+        auto kp = adlhip::msd2s_offsets_kernel<uint64_t, CP::TILE, 512, 16, 1, 4>;
+        int c = 0;
         if (ensure_lds(ks, lds_s) == ADLHIP_SUCCESS && ensure_lds(ko, CO::LDS_BYTES) == ADLHIP_SUCCESS &&
+            ensure_lds(kp, CP::LDS_BYTES) == ADLHIP_SUCCESS &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(ks), 512, lds_s) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(ko), 512, CO::LDS_BYTES) == hipSuccess)
-            d->resident_wgs = std::min(a, b) * d->prop.multiProcessorCount;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(ko), 512, CO::LDS_BYTES) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, reinterpret_cast<const void*>(kp), 512, CP::LDS_BYTES) == hipSuccess)
+            d->resident_wgs = std::min(std::min(a, b), c) * d->prop.multiProcessorCount;
         else
             d->resident_wgs = d->prop.multiProcessorCount;   // one per CU at least
         d->resident_wgs_device = d->resident_wgs;

@@ -9,6 +9,9 @@ namespace adlhip {
 constexpr int kDictMax = 256;       // values the dictionary holds
 constexpr int kDictSlots = 1024;    // hash slots over them (load <= 1/4)
 constexpr unsigned long long kDictEmpty = ~0ull;
+// The net tries the dictionary only if the sort's first kernel (hybrid_kernels.hpp sample_accumulate) counted this many repeats among
+// its 16 x 128 samples: keys of 256 equally likely values show 16 (128 - 256 (1 - e^(-1/2))) = 436 +- 20, skewed or fewer values more.
+constexpr uint32_t kDictMinRepeats = 256u;
 
 struct DictBlock {                                  // handle-owned device memory
     uint32_t n_values;                              // 0: the sampled keys take more than kDictMax values (no dictionary)

@@ -6,8 +6,9 @@
 // value with a million copies outgrows any slab: such keys end in its safety net (net_sort, hybrid_kernels.hpp), whose ordinary
 // work is four LSD passes (about 1 ms for 64 Mi keys).  Counting needs one read and one write of the array.  Equal keys are
 // indistinguishable, so the output of a sort of whole keys is determined by the counts alone; it is bit for bit what the
-// reference's CPU sort (Tahoe/Algorithm/Sort/RadixSort.cpp:58-104) produces.  ({key, value} pairs and sorts on part of the key
-// go straight to the LSD passes: there equal keys are not interchangeable.)
+// reference's CPU sort (Tahoe/Algorithm/Sort/RadixSort.cpp:58-104) produces.  (Equal keys of {key, value} pairs are not
+// interchangeable: pairs with few-valued keys take ONE stable pass on the key's rank in the same dictionary -- the last part of
+// this file; sorts on part of the key go straight to the LSD passes.)
 //
 // Round 4: the three steps are phases of the net itself, separated by its grid barriers (round 3: three launches chosen by a
 // host-side hint that a probe launch had left behind):
@@ -198,5 +199,110 @@ __device__ __forceinline__ bool dict_fill_range(E* __restrict__ data, uint32_t n
     }
     return true;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// {key, value} pairs whose KEYS take few distinct values (round 4).  Equal keys of pairs are not interchangeable, so counting alone
+// does not sort them -- but ONE stable pass on the key's rank in the dictionary does, where the LSD passes need four: the net
+// (hybrid_kernels.hpp coop_dict_pair_sort) counts ranks while it copies the pairs -- as {rank, value} -- to the scratch array, then
+// scatters them back with the ordinary tile body sorting on bits [0, 8); DictPairIO below puts the keys back in the stores.
+// The rank comes from a 4096-slot hash table over the (at most 256) values (load 1/16: the first probe nearly always ends the
+// search -- with 512 slots the 64 lanes of a wave waited for the longest of their probe chains, 64 Mi pairs of 256 values 0.9-1.2
+// ms); a slot holds key and rank together (ONE 8-byte LDS read per probe).  32 KiB, in the tile's element area: only the count
+// phase looks ranks up, and the tile is not in use then.  The values themselves, for the way back, take 1 KiB of static LDS.
+// ------------------------------------------------------------------------------------------
+constexpr int kPairSlots = 4096;
+constexpr unsigned long long kPairFree = 0x00000000ffffffffull;   // slot = rank << 32 | key; the all-ones key never enters the table
+__device__ __forceinline__ uint32_t pair_dict_hash(uint32_t key)   // 12 bits; two rounds: values are often multiples or masks of each other
+{
+    uint32_t h = key * 0x9E3779B1u;
+    h ^= h >> 15;
+    return (h * 0x85EBCA6Bu) >> 20;
+}
+// what the first probe (slot `s0` = s_slot[pair_dict_hash(key)], read by the caller: it reads the slots of all its keys first and
+// looks at them afterwards, so that the LDS latencies overlap) leaves to do.  Returns the rank of `key`, or 0xffffffff.
+// max_rank: rank of the all-ones key if it is a value, else 0xffffffff.
+__device__ __forceinline__ uint32_t pair_dict_rank(uint32_t key, unsigned long long s0, const unsigned long long* __restrict__ s_slot,
+                                                   uint32_t max_rank)
+{
+    if (key == 0xffffffffu) return max_rank;
+    if ((uint32_t)s0 == key) return (uint32_t)(s0 >> 32);
+    if ((uint32_t)s0 == 0xffffffffu) return 0xffffffffu;
+    uint32_t h = (pair_dict_hash(key) + 1u) & (uint32_t)(kPairSlots - 1);
+    for (int step = 1; step < kPairSlots; ++step) {
+        const unsigned long long s = s_slot[h];
+        if ((uint32_t)s == key) return (uint32_t)(s >> 32);
+        if ((uint32_t)s == 0xffffffffu) return 0xffffffffu;
+        h = (h + 1u) & (uint32_t)(kPairSlots - 1);
+    }
+    return 0xffffffffu;
+}
+// all threads of a workgroup (NT >= 256): the tables from the dictionary block (s_val [256]: the values in ascending order, padded
+// with 0xffffffff); returns max_rank; barriers inside and at the end
+template <int NT>
+__device__ __forceinline__ uint32_t pair_dict_load(const DictBlock* __restrict__ blk, uint32_t nv, uint32_t* s_val, unsigned long long* s_slot)
+{
+    const int tid = (int)threadIdx.x;
+    for (int i = tid; i < kPairSlots; i += NT) s_slot[i] = kPairFree;
+    const unsigned long long mine = (uint32_t)tid < nv ? blk->value[tid] : kDictEmpty;
+    if (tid < 256) s_val[tid] = (uint32_t)mine;   // (kDictEmpty narrows to the all-ones key)
+    __syncthreads();
+    if ((uint32_t)tid < nv && mine != kDictEmpty) {
+        uint32_t h = pair_dict_hash((uint32_t)mine);
+        for (int step = 0; step < kPairSlots; ++step) {
+            if (atomicCAS(&s_slot[h], kPairFree, ((unsigned long long)(uint32_t)tid << 32) | (uint32_t)mine) == kPairFree) break;
+            h = (h + 1u) & (uint32_t)(kPairSlots - 1);
+        }
+    }
+    const uint32_t max_rank = blk->value[nv - 1u] == kDictEmpty ? nv - 1u : 0xffffffffu;   // (ascending: the all-ones key is the last)
+    __syncthreads();
+    return max_rank;
+}
+
+// ONE workgroup: 16 Ki sampled KEYS of pairs (n >= 16384) -> the dictionary, or n_values = 0
+template <int NT>
+__device__ __forceinline__ void dict_sample_build_pair_keys(const uint64_t* __restrict__ src, uint32_t n, DictBlock* __restrict__ blk,
+                                                            unsigned char* smem)
+{
+    constexpr int PER = 16384 / NT;
+    unsigned long long v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t x = (uint32_t)src[probe_sample_index((uint32_t)((int)threadIdx.x * PER + i), n)];
+        v[i] = x == 0xffffffffu ? kDictEmpty : (unsigned long long)x;
+    }
+    dict_build<PER, NT>(v, blk, smem);
+}
+
+// AoS pairs that hold the RANK of their key where the key was (the count phase of coop_dict_pair_sort wrote them so): loads are
+// plain, stores translate rank -> key (radix_kernels.hpp AosIO is the model).  (Looking the rank up in the loads instead -- sixteen
+// unrolled probe loops in the tile body -- spilled registers: 64 Mi pairs of 256 values 2.3 ms.)
+struct DictPairIO {
+    typedef uint64_t elem_t;
+    const uint64_t* src;
+    uint64_t* dst;
+    const uint32_t* s_val;   // LDS [256]: the value of rank r
+    struct Cursor {
+        const uint64_t* p;
+        __device__ __forceinline__ uint64_t at(int off) const { return load_once(p + off); }
+    };
+    __device__ __forceinline__ Cursor cursor(size_t base) const { return Cursor{src + base}; }
+    __device__ __forceinline__ void store(size_t i, uint64_t v) const { dst[i] = (v & 0xffffffff00000000ull) | s_val[(uint32_t)v & 255u]; }
+    static constexpr uint32_t kStoreScale = 8u;
+    struct Dst {
+        __amdgpu_buffer_rsrc_t r;
+        const uint32_t* s_val;
+    };
+    __device__ __forceinline__ Dst make_dst(uint32_t n) const
+    {
+        return Dst{__builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(n * 8u), 0x00020000), s_val};
+    }
+    static __device__ __forceinline__ void store_at(const Dst& d, uint32_t byte_off, uint64_t v)
+    {
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t t = {d.s_val[(uint32_t)v & 255u], (uint32_t)(v >> 32)};
+        __builtin_amdgcn_raw_buffer_store_b64(t, d.r, (int)byte_off, 0, 0);
+    }
+};
 
 }  // namespace adlhip

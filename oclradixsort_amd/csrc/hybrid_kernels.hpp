@@ -63,6 +63,20 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t& target
     return ok != 0u;
 }
 
+// The large sort's words beside its overflow flag (flag = d_msd2 + 8192 + 65536; adlhip.hip): flag[12] = samples of the sort's
+// first kernel that repeat an earlier one of their wave (sample_accumulate), flag[14] = how many of them mean "these keys cannot
+// fit the slabs" (the host's sample_dup_threshold, passed on by the first kernel).  Every later kernel of the sort asks this at its
+// first instruction: set = the passes have nothing to do, the offsets kernel runs the net.
+constexpr int kSampleRepeatsWord = 12;
+constexpr int kSampleThresholdWord = 14;
+__device__ __forceinline__ uint32_t large_sort_gave_up(const uint32_t* flag)
+{
+    const uint32_t over = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t reps = __hip_atomic_load(flag + kSampleRepeatsWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t thr = __hip_atomic_load(flag + kSampleThresholdWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return over | (reps >= thr ? 1u : 0u);
+}
+
 struct MidCoop {          // what the safety net needs beside the two arrays (table == nullptr: there is none)
     uint32_t* table;      // [256][gridDim.x] bucket-major digit table
     uint32_t* totals;     // [256]
@@ -292,6 +306,140 @@ __device__ __forceinline__ bool coop_onesweep_sort(E* data, E* tmp, uint32_t n, 
     return true;
 }
 
+// {key, value} pairs whose keys take at most 256 values (the dictionary `blk` holds them, nv of them; dict_kernels.hpp): ONE stable
+// pass on the key's rank where the LSD passes need four.  The shape is one pass of coop_lsd_sort with two differences: the count
+// phase looks ranks up and copies the workgroup's run of tiles to `tmp` as it goes, each key replaced by its rank (the scatter then
+// goes tmp -> data: the result belongs in `data`, and a copy back afterwards would read and write everything once more), and the
+// scatter phase sorts on bits [0, 8) and puts the keys back as it stores (DictPairIO).  A workgroup scatters the tiles it copied itself, so the copy needs no fence.
+// Returns 1: sorted; 0: some key is not in the dictionary -- `data` is untouched, the caller's LSD passes sort; -1: a barrier gave up.
+template <int NT, int K, int RANK>
+__device__ __forceinline__ int coop_dict_pair_sort(uint64_t* data, uint64_t* tmp, uint32_t n, uint32_t* __restrict__ table,
+                                                   uint32_t* __restrict__ totals, uint32_t* bar, uint32_t& target, uint32_t* fault,
+                                                   unsigned char* smem, DictBlock* __restrict__ blk, uint32_t nv, uint32_t* s_val /* static LDS [256] */)
+{
+    using C = TileCfg<uint64_t, 8, NT, K>;
+    constexpr int NW = NT / 64;
+    static_assert(NT >= 256, "one thread per value");
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem + C::OFF_WCNT);   // [NW][256]
+    uint32_t* s_wsum = reinterpret_cast<uint32_t*>(smem + C::OFF_WSUM);
+    const int tid = (int)threadIdx.x;
+    const int w = tid >> 6;
+    const uint32_t wg = blockIdx.x, wgs = gridDim.x;
+    const uint32_t tiles = (n + (uint32_t)C::TILE - 1u) / (uint32_t)C::TILE;
+    const uint32_t per = (tiles + wgs - 1u) / wgs;
+    const uint32_t t0 = wg * per < tiles ? wg * per : tiles;
+    const uint32_t t1 = t0 + per < tiles ? t0 + per : tiles;
+    const uint32_t e0 = t0 * (uint32_t)C::TILE;   // (workgroups beyond the last tile: t0 = t1 = tiles, e0 >= n)
+    const uint32_t e1 = (uint64_t)t1 * C::TILE < n ? t1 * (uint32_t)C::TILE : n;
+    const uint32_t len = e1 > e0 ? e1 - e0 : 0u;
+    auto tab_ld = [](const uint32_t* p) -> uint32_t { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto tab_st = [](uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // the hash table lies in the tile's element area, which the count phase does not use (32 KiB: 4096 slots of {key, rank})
+    unsigned long long* s_slot = reinterpret_cast<unsigned long long*>(smem + C::OFF_ELEMS);
+    static_assert(8 * kPairSlots <= (int)(C::OFF_WCNT - C::OFF_ELEMS), "the hash table fits the element area");
+    const uint32_t max_rank = pair_dict_load<NT>(blk, nv, s_val, s_slot);
+    const bool one_value = nv == 1u;   // every key the same (if none misses): nothing to move
+    for (int i = tid; i < NW * 256; i += NT) hist[i] = 0u;
+    __syncthreads();
+    // ---- count the ranks of this workgroup's run of tiles, copying it to tmp ---------------------------------------------
+    {
+        uint32_t* my = hist + w * 256;
+        bool miss = false;
+        // a lane counts runs of equal ranks by itself and adds a run at its end: constant and ordered keys would otherwise queue 64
+        // lanes on one LDS counter, element after element
+        uint32_t cur = 0u, run = 0u;
+        auto count = [&](uint32_t r) {
+            if (r == cur) {
+                ++run;
+            } else {
+                if (run) atomicAdd(&my[cur], run);
+                cur = r;
+                run = 1u;
+            }
+        };
+        struct alignas(16) V2 { uint64_t v[2]; };
+        const V2* vs = reinterpret_cast<const V2*>(data + e0);   // e0 is a multiple of the tile: 16-byte aligned
+        V2* vd = reinterpret_cast<V2*>(tmp + e0);
+        const uint32_t nvec = len / 2u;
+        constexpr int U = 4;
+        for (uint32_t i0 = (uint32_t)tid; i0 < nvec; i0 += (uint32_t)(U * NT)) {
+            V2 v[U];
+            bool act[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                act[u] = i0 + (uint32_t)(u * NT) < nvec;
+                if (act[u]) v[u] = vs[i0 + (uint32_t)(u * NT)];
+                else v[u].v[0] = v[u].v[1] = 0ull;
+            }
+            unsigned long long s0[2 * U];   // first probes of all eight keys, then the looks at them
+#pragma unroll
+            for (int j = 0; j < 2 * U; ++j) s0[j] = s_slot[pair_dict_hash((uint32_t)v[j >> 1].v[j & 1])];
+#pragma unroll
+            for (int j = 0; j < 2 * U; ++j) {
+                uint64_t& x = v[j >> 1].v[j & 1];
+                const uint32_t r = pair_dict_rank((uint32_t)x, s0[j], s_slot, max_rank);
+                if (act[j >> 1]) {
+                    if (r == 0xffffffffu) miss = true;
+                    else count(r);
+                }
+                x = (x & 0xffffffff00000000ull) | (r & 255u);   // the rank where the key was
+            }
+            if (!one_value) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (act[u]) vd[i0 + (uint32_t)(u * NT)] = v[u];
+            }
+        }
+        if (tid == 0 && (len & 1u)) {   // an odd element ends the array
+            uint64_t x = data[e1 - 1u];
+            const uint32_t r = pair_dict_rank((uint32_t)x, s_slot[pair_dict_hash((uint32_t)x)], s_slot, max_rank);
+            if (r == 0xffffffffu) miss = true;
+            else count(r);
+            if (!one_value) tmp[e1 - 1u] = (x & 0xffffffff00000000ull) | (r & 255u);
+        }
+        if (run) atomicAdd(&my[cur], run);
+        const int any_miss = __syncthreads_or(miss);
+        if (any_miss && tid == 0) __hip_atomic_store(&blk->miss, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 256) {
+            uint32_t c = 0u;
+            for (int i = 0; i < NW; ++i) c += hist[i * 256 + tid];
+            tab_st(&table[(size_t)tid * wgs + wg], c);
+        }
+    }
+    if (!grid_barrier(bar, target, wgs, fault, false)) return -1;
+    if (__hip_atomic_load(&blk->miss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;   // (the same word for every workgroup)
+    if (one_value) return 1;
+    // ---- workgroup d scans row d ------------------------------------------------------------------------------------------
+    for (uint32_t d = wg; d < 256u; d += wgs) {
+        uint32_t carry = 0u;
+        for (uint32_t base = 0; base < wgs; base += (uint32_t)NT) {
+            const uint32_t j = base + (uint32_t)tid;
+            const uint32_t v = j < wgs ? tab_ld(&table[(size_t)d * wgs + j]) : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan_u32<NT>(v, s_wsum, &tot);
+            if (j < wgs) tab_st(&table[(size_t)d * wgs + j], carry + ex);
+            carry += tot;
+        }
+        if (tid == 0) tab_st(&totals[d], carry);
+    }
+    if (!grid_barrier(bar, target, wgs, fault, false)) return -1;
+    // ---- scatter this workgroup's tiles tmp -> data, carrying per-rank offsets from tile to tile ---------------------------
+    {
+        const uint32_t tot_d = tid < 256 ? tab_ld(&totals[tid]) : 0u;
+        const uint32_t base_d = block_excl_scan_u32<NT>(tot_d, s_wsum, nullptr);
+        uint32_t carry = tid < 256 ? base_d + tab_ld(&table[(size_t)tid * wgs + wg]) : 0u;
+        const DictPairIO io{tmp, data, s_val};
+        for (uint32_t t = t0; t < t1; ++t) {
+            const uint32_t tb = t * (uint32_t)C::TILE;
+            const uint32_t left = n - tb;
+            const uint32_t valid = left < (uint32_t)C::TILE ? left : (uint32_t)C::TILE;
+            sort_scatter_tile<DictPairIO, 8, NT, K, RANK>(io, tb, valid, n, 0, smem,
+                                                          [&](int, uint32_t c) { const uint32_t g = carry; carry += c; return g; });
+        }
+    }
+    return 1;
+}
+
 // The large sort's safety net, run by the workgroups of its offsets kernel when a run did not fit its slab (the input is then
 // untouched: the passes write only slabs).  dict != nullptr (whole-key sorts of keys): first the counting sort of
 // dict_kernels.hpp -- sample, look up and count, fill -- and only if the keys take more than 256 values, or one of them missed the
@@ -300,17 +448,30 @@ __device__ __forceinline__ bool coop_onesweep_sort(E* data, E* tmp, uint32_t n, 
 template <typename E, int NT, int K, int RANK = 1, int P = 0>
 __device__ __forceinline__ void net_sort(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table, uint32_t* bar, uint32_t* fault,
                                          unsigned char* smem, int key_bits, DictBlock* dict, uint32_t* stats, const OsNet& os,
+                                         uint32_t sample_repeats /* of the sort's first kernel: keys of <= 256 values show ~126, at least 64 */,
                                          uint32_t target0 = 0u)
 {
     uint32_t target = target0;
     const uint32_t wgs = gridDim.x;
     // stats[0] = nets run, stats[1] = of those, sorted by counting ("stat.net_runs" / "stat.net_counting": tests, bench)
     if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(stats + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (dict && n >= 16384u) {
-        if (blockIdx.x == 0) dict_sample_build<E, NT>(data, n, dict, smem);
+    constexpr bool PAIRS = sizeof(E) == 8 && P == 4;   // {key, value} pairs (u64 keys: P == 8)
+    if (dict && n >= 16384u && sample_repeats >= kDictMinRepeats) {
+        if (blockIdx.x == 0) {
+            if constexpr (PAIRS) dict_sample_build_pair_keys<NT>(data, n, dict, smem);
+            else dict_sample_build<E, NT>(data, n, dict, smem);
+        }
         if (!grid_barrier(bar, target, wgs, fault)) return;
         const uint32_t nv = __hip_atomic_load(&dict->n_values, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (nv) {
+        if constexpr (PAIRS) {
+            if (nv) {   // one stable pass on the key's rank among the values
+                __shared__ uint32_t s_val[256];
+                const int done = coop_dict_pair_sort<NT, K, RANK>(data, tmp, n, table, table + 256 * wgs, bar, target, fault, smem, dict, nv, s_val);
+                if (done == 1 && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(stats + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (done != 0) return;
+                __syncthreads();   // (a key missed the dictionary: the LSD passes sort the untouched input)
+            }
+        } else if (nv) {
             dict_count_range<E, NT>(data, n, dict, nv, smem);
             if (!grid_barrier(bar, target, wgs, fault)) return;
             if (!__hip_atomic_load(&dict->miss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && dict_fill_range<E, NT>(data, n, dict, nv, smem)) {
@@ -1218,30 +1379,95 @@ ADLHIP_KERNEL __global__ __launch_bounds__(1024) void probe_positions_selftest_k
     if (bad) atomicAdd(out + 1, bad);
 }
 
+// ------------------------------------------------------------------------------------------
+// The first kernel of a large sort: 2048 sampled keys, two per lane of 16 one-wave workgroups.  They place the digits (OR / AND into
+// the handle's four sample words, below) and they show what the passes would otherwise find out by moving keys (64 Mi keys of 256
+// values: 0.2 ms before the net starts): keys that repeat a few thousand values cannot fit the slabs (a value with more copies than
+// a segment slab holds).  Every wave counts the samples that repeat an earlier one of ITS 128 (D distinct values: 128 - D (1 -
+// e^(-128/D)) of them, ~8000 / D; 32-bit fingerprints in an LDS table: two different keys share one with probability 2^-31)
+// and adds the count -- if it is not zero -- to flag[kSampleRepeatsWord]; the kernels behind compare the sum with the threshold the
+// host computed from n (adlhip.hip sample_dup_threshold; never below 4 where keys without repeats show 0; large_sort_gave_up): the
+// passes leave at their first instruction and the net starts at once.  No state, no report: the same input is treated the same way
+// every time.  Fewer than kDictMinRepeats and the net does not try its dictionary.  The offsets kernel puts the word back to zero.
+// Cost: the second key per lane and two LDS compare-and-swaps, ~1-2 us of 8.  Tried and dropped: 1024 samples in ONE
+// workgroup (LDS table of fingerprints + first-digit histogram for "one bucket holds 1/16 of the keys"): 1024 scattered loads from
+// one compute unit queue up behind its address translation -- 10-11 us against 6, 1.6 % of a 64-Mi-key sort on every input
+// (same-box A/B); sixteen workgroups handing their samples to the last one for that digest: 19 us; the sixteen waves' counts summed
+// by the last to arrive (one returning atomic behind an s_waitcnt): 9 us.
 constexpr int kSampleWGs = 16;
+constexpr int kSamples = 2048;
+constexpr int kSampleArriveWord = 13;    // flag[13]: workgroups of msd2s_prep_kernel that have arrived (zero when idle)
 
-template <typename E>
-__global__ __launch_bounds__(64) void msd2_sample_kernel(const E* __restrict__ src, uint32_t n, uint32_t* sample, uint32_t* bar,
-                                                         uint32_t* fault)
+// where sample `k` of 2048 is read: its 1/2048th of the input, at a scrambled offset inside (evenly spaced positions meet keys
+// generated from their index -- i * c >> s and the like -- at values that never repeat, whatever the input holds)
+__device__ __forceinline__ size_t sample_position(int k, uint32_t n)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {   // the safety net's grid-barrier counter (used, if at all, in the offsets kernel)
-        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fault[0] = 0u;   // the live fault word: the first kernel of every sort clears it (include/adlhip.h)
-    }
-    const unsigned long long k = (unsigned long long)(blockIdx.x * 64u + threadIdx.x);
-    const unsigned long long v = (unsigned long long)src[(size_t)(k * (unsigned long long)n / (unsigned long long)(kSampleWGs * 64))];
-    unsigned long long o = v, a = v;
+    const unsigned long long lo = (unsigned long long)k * n / (unsigned)kSamples, hi = (unsigned long long)(k + 1) * n / (unsigned)kSamples;
+    uint32_t h = (uint32_t)k * 0x85EBCA6Bu + 0x27D4EB2Fu;
+    h ^= h >> 15;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 13;
+    return (size_t)(lo + (((unsigned long long)h * (hi - lo)) >> 32));   // in [lo, hi) (or lo); multiply-and-shift, no remainder
+}
+
+// Every lane of the 16 one-wave workgroups, with its two (masked) samples: OR / AND into sample[0..3] (or lo, or hi, and lo, and
+// hi: idle values 0 / ~0), the wave's repeats into flag[kSampleRepeatsWord].
+__device__ __forceinline__ void sample_accumulate(unsigned long long v0, unsigned long long v1, uint32_t* sample, uint32_t* flag)
+{
+    const int lane = (int)threadIdx.x;
+    unsigned long long o = v0 | v1, a = v0 & v1;
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) {
         o |= __shfl_xor(o, sh);
         a &= __shfl_xor(a, sh);
     }
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         __hip_atomic_fetch_or(sample + 0, (uint32_t)o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_or(sample + 1, (uint32_t)(o >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_and(sample + 2, (uint32_t)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_and(sample + 3, (uint32_t)(a >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // repeats among the wave's 128 samples: fingerprints (never 0) into a 256-slot LDS table; an insert that finds its own fingerprint
+    // there is a repeat.  One wave: its LDS operations execute in order, no barrier.  (Lane-by-lane compares through v_readlane: 126
+    // of them and 250 compares, ~1 us of a 7-us kernel.)
+    __shared__ uint32_t s_seen[256];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_seen[i * 64 + lane] = 0u;
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const unsigned long long hv = ((j ? v1 : v0) + 0x632BE59BD9B4E019ull) * 0x9E3779B97F4A7C15ull;
+        const uint32_t fp = (uint32_t)(hv >> 32) | 1u;
+        uint32_t h = (uint32_t)(hv >> 24) & 255u;
+        for (int step = 0; step < 256; ++step) {
+            const uint32_t old = atomicCAS(&s_seen[h], 0u, fp);
+            if (old == 0u) break;
+            if (old == fp) {
+                ++mine;
+                break;
+            }
+            h = (h + 1u) & 255u;
+        }
+    }
+    uint32_t reps = mine;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) reps += __shfl_xor(reps, sh);
+    if (lane == 0 && reps) __hip_atomic_fetch_add(flag + kSampleRepeatsWord, reps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename E>
+__global__ __launch_bounds__(64) void msd2_sample_kernel(const E* __restrict__ src, uint32_t n, uint32_t* sample, uint32_t* bar,
+                                                         uint32_t* fault, uint32_t* flag, uint32_t dup_thr)
+{
+    const int tid = (int)(blockIdx.x * 64u + threadIdx.x);
+    if (tid == 0) {   // the safety net's grid-barrier counter (used, if at all, in the offsets kernel)
+        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fault[0] = 0u;   // the live fault word: the first kernel of every sort clears it (include/adlhip.h)
+        __hip_atomic_store(flag + kSampleThresholdWord, dup_thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (this form sorts whole keys; its offsets kernel puts the sample words back to their idle values)
+    const E x0 = src[sample_position(2 * tid, n)], x1 = src[sample_position(2 * tid + 1, n)];
+    sample_accumulate((unsigned long long)x0, (unsigned long long)x1, sample, flag);
 }
 
 // The tile body is the one-sweep pass's (onesweep_kernels.hpp onesweep_chain_kernel) without its ticket, status rows and
@@ -1269,7 +1495,7 @@ __global__ __launch_bounds__(NT) void msd_bucket_scatter_kernel(BucketPass<E> a)
     // workgroup of which some waves have left would go on with stale counters)
     uint32_t give_up = 0u;
     if constexpr (PASS >= 1) {
-        if (threadIdx.x == 0) give_up = __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) give_up = large_sort_gave_up(a.flag);
     }
     uint32_t base, valid, cursor_base = 0u;
     uint32_t lin = 0u;   // PASS == 3: index of the tile's first element if the tile lies inside one sub-slab, else ~0
@@ -1548,7 +1774,8 @@ __global__ __launch_bounds__(NT) void msd2_offsets_kernel(uint32_t* cursors_a, u
     const int t = (int)threadIdx.x;
     const uint32_t b = blockIdx.x;   // the grid has at least 256 workgroups: workgroup b < 256 serves bucket b
     // final since pass 2 has completed; every workgroup reads it BEFORE it counts itself done, the last one done clears it
-    const uint32_t overflow = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t overflow = large_sort_gave_up(flag);
+    const uint32_t sample_repeats = __hip_atomic_load(flag + kSampleRepeatsWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (b < 256u) {
         const uint32_t ca = t < 256 ? __hip_atomic_load(cursors_a + 32 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;   // one line per cursor
         const uint32_t exa = block_excl_scan_u32<NT>(ca, s_wsum, nullptr);
@@ -1580,12 +1807,13 @@ __global__ __launch_bounds__(NT) void msd2_offsets_kernel(uint32_t* cursors_a, u
                 __hip_atomic_store(sample + 3, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flag + kSampleRepeatsWord, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (overflow) {   // `bar` is zero here: msd2_sample_kernel, the first launch of every sort, clears it
         __syncthreads();
-        net_sort<E, NT, K, 1, (int)sizeof(E)>(data, tmp, n, ctable, bar, fault, smem, key_bits, dict, stats, os);
+        net_sort<E, NT, K, 1, (int)sizeof(E)>(data, tmp, n, ctable, bar, fault, smem, key_bits, dict, stats, os, sample_repeats);
     }
 }
 
@@ -1606,38 +1834,42 @@ __global__ __launch_bounds__(NT) void msd2_offsets_kernel(uint32_t* cursors_a, u
 //           keys-only form; the safety net is the same cooperative LSD sort.
 // Tickets give tile indices in arrival order, so a tile only ever waits for tiles that already run.
 // ------------------------------------------------------------------------------------------
-// one workgroup: sample 1024 keys -> digit placement; clear the tickets of both passes.  Only the low sort_bits bits of a key take
-// part in the sort (Pprims.cpp:357: the passes cover bits [0, sortBits)); the digits are placed inside them.
+// 16 one-wave workgroups (see msd2_sample_kernel): sample 2048 keys -> digit placement; clear the tickets of both passes.  Only the
+// low sort_bits bits of a key take part in the sort (Pprims.cpp:357: the passes cover bits [0, sortBits)); the digits are placed
+// inside them, and the sample is looked at as it counts for this sort: the KEY of a pair, masked to the sorted bits.  The last
+// workgroup to arrive turns the four sample words into `place` and puts them back to their idle values.
 template <typename E, bool KEY64>
-__global__ __launch_bounds__(1024) void msd2s_prep_kernel(const E* __restrict__ src, uint32_t n, StablePlace* __restrict__ place,
-                                                           uint32_t* __restrict__ tickets, uint32_t ticket_words, uint32_t* bar,
-                                                           uint32_t* fault, uint32_t sort_bits)
+__global__ __launch_bounds__(64) void msd2s_prep_kernel(const E* __restrict__ src, uint32_t n, StablePlace* __restrict__ place,
+                                                         uint32_t* __restrict__ tickets, uint32_t ticket_words, uint32_t* bar,
+                                                         uint32_t* fault, uint32_t sort_bits, uint32_t* flag, uint32_t dup_thr)
 {
-    __shared__ unsigned long long s_or[16], s_and[16];
-    const int tid = (int)threadIdx.x;
+    const int tid = (int)(blockIdx.x * 64u + threadIdx.x);
     if (tid == 0) {
         __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the safety net's grid-barrier counter
         fault[0] = 0u;   // the live fault word: the first kernel of every sort clears it (the look-back's waiters poll it)
+        __hip_atomic_store(flag + kSampleThresholdWord, dup_thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    for (uint32_t i = (uint32_t)tid; i < ticket_words; i += 1024u) tickets[i] = 0u;
     const unsigned long long kmask = sort_bits >= 64u ? ~0ull : ((1ull << sort_bits) - 1ull);
-    const unsigned long long v = key_of<KEY64>(src[(size_t)((unsigned long long)tid * n / 1024ull)]) & kmask;
-    unsigned long long o = v, a = v;
-#pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) {
-        o |= __shfl_xor(o, sh);
-        a &= __shfl_xor(a, sh);
-    }
-    if ((tid & 63) == 0) {
-        s_or[tid >> 6] = o;
-        s_and[tid >> 6] = a;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (int i = 1; i < 16; ++i) {
-            o |= s_or[i];
-            a &= s_and[i];
-        }
+    const E x0 = src[sample_position(2 * tid, n)], x1 = src[sample_position(2 * tid + 1, n)];
+    for (uint32_t i = (uint32_t)tid; i < ticket_words; i += 64u * (uint32_t)kSampleWGs) tickets[i] = 0u;
+    uint32_t* sample = flag + 8;
+    sample_accumulate(key_of<KEY64>(x0) & kmask, key_of<KEY64>(x1) & kmask, sample, flag);
+    // the workgroup that arrives last finds all sixteen contributions in the sample words (agent-scope atomics, each wave's complete
+    // at its s_waitcnt before it arrives)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t arrived = 0u;
+    if (threadIdx.x == 0) arrived = __hip_atomic_fetch_add(flag + kSampleArriveWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)arrived) != (uint32_t)kSampleWGs - 1u) return;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(flag + kSampleArriveWord, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long o = ((unsigned long long)__hip_atomic_load(sample + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32) |
+                                     __hip_atomic_load(sample + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long a = ((unsigned long long)__hip_atomic_load(sample + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32) |
+                                     __hip_atomic_load(sample + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sample + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sample + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sample + 2, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sample + 3, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long diff = o ^ a;
         uint32_t top = diff ? 64u - (uint32_t)__builtin_clzll(diff) : 0u;
         if (top < 16u) top = 16u;
@@ -1702,9 +1934,11 @@ __global__ __launch_bounds__(NT) void msd_lookback_scatter_kernel(LookbackPass<E
 
     // ---- ticket -> tile index in the chain -> where the tile's elements are ------------------------------------------------
     if (w == 0) {
-        // pass B once the overflow flag is up (pass A's, or an earlier tile's of this pass): the net will sort (net_sort); wave 0
+        // once the overflow flag is up (the sample's, pass A's, or an earlier tile's of this pass): the net will sort (net_sort); wave 0
         // decides for the workgroup -- no ticket, valid = 0, everybody leaves behind the barrier below
-        const bool give_up = a.which_digit == 2 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
+        // (pass A too: the sample may have raised the flag before the first tile, and a tile that takes its ticket after the flag rose
+        // has only successors that do the same -- nobody waits for its status row)
+        const bool give_up = __builtin_amdgcn_readfirstlane((int)large_sort_gave_up(a.flag)) != 0;
         uint32_t index = 0u;
         if (lane == 0 && !give_up) index = atomicAdd(&a.tickets[chain * (uint32_t)kTicketStride], 1u);
         index = (uint32_t)__builtin_amdgcn_readfirstlane((int)index);
@@ -1966,7 +2200,8 @@ __global__ __launch_bounds__(NT) void msd2s_offsets_kernel(const uint32_t* __res
     const int t = (int)threadIdx.x;
     const uint32_t b = blockIdx.x;   // at least 256 workgroups: workgroup b < 256 serves bucket b
     // final since pass B has completed; read by every workgroup BEFORE it counts itself done, cleared by the last one done
-    const uint32_t overflow = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t overflow = large_sort_gave_up(flag);
+    const uint32_t sample_repeats = __hip_atomic_load(flag + kSampleRepeatsWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (b < 256u) {
     // thread t: size of bucket t = sum of its 16 sub-slabs; and the tiles pass B made of it
     uint32_t size_t_ = 0u, tiles_t = 0u;
@@ -2011,6 +2246,7 @@ __global__ __launch_bounds__(NT) void msd2s_offsets_kernel(const uint32_t* __res
         mode[kDynHardCnt] = 0u;
         seg_off[65536] = n;
         __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flag + kSampleRepeatsWord, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (overflow) {   // `bar` is zero here: msd2s_prep_kernel, the first launch of every sort, clears it
@@ -2023,7 +2259,8 @@ __global__ __launch_bounds__(NT) void msd2s_offsets_kernel(const uint32_t* __res
                 if (!grid_barrier(bar, target, gridDim.x, fault)) return;
             }
         }
-        net_sort<E, NT, K, RANK, P>(data, tmp, n, ctable, bar, fault, smem, (int)place->sort_bits, soa_keys ? nullptr : dict, stats, os, target);
+        net_sort<E, NT, K, RANK, P>(data, tmp, n, ctable, bar, fault, smem, (int)place->sort_bits, soa_keys ? nullptr : dict, stats, os,
+                                    sample_repeats, target);
         if constexpr (sizeof(E) == 8) {
             if (soa_keys) {   // the sort's last phase ends with a grid barrier: `data` is complete
                 for (size_t i = (size_t)blockIdx.x * NT + (size_t)t; i < n; i += (size_t)gridDim.x * NT) {

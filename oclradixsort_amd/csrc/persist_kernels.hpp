@@ -141,8 +141,8 @@ __global__ __launch_bounds__(NT, WPE) void msd_scatter_persist_kernel(BucketPass
     // workgroup of which some waves have left would go on with stale counters and tickets: one thread's (one tile ago: every wave's)
     // view goes through LDS and a barrier.
     uint32_t* __restrict__ s_give = reinterpret_cast<uint32_t*>(smem + C::OFF_WSUM);   // [8 + 1] (the block scan's scratch: prologue only)
-    if constexpr (PASS >= 2) {
-        if (tid == 0) s_give[8] = __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {   // (pass 1 too: the sample kernel raises the flag for keys that repeat a few thousand values)
+        if (tid == 0) s_give[8] = large_sort_gave_up(a.flag);
         __syncthreads();
         if (s_give[8]) return;
         __syncthreads();   // (the scan below reuses the scratch)

@@ -1892,19 +1892,137 @@ def test_counting_sort_for_keys_with_few_distinct_values():
         few = vals32(16)[rng.randint(0, 16, n)]
         pairs = few.astype(np.uint64) | (np.arange(n, dtype=np.uint64) << np.uint64(32))
         assert np.array_equal(gpu_sort_kv(d, p, pairs), oracle.sort_kv32(pairs))
-        assert _net_stats(d) == (2, 0)
+        assert _net_stats(d) == (2, 1)   # (pairs: one stable pass on the key's rank in the dictionary, test_pairs_with_few_valued_keys...)
+        assert np.array_equal(gpu_sort_kv(d, p, pairs, 24), oracle.sort_e64_bits(pairs, 24))
+        assert _net_stats(d) == (3, 1)
         assert np.array_equal(gpu_sort_u32(d, p, few, 24), oracle.sort_u32_bits(few, 24))
-        assert _net_stats(d) == (3, 0)
+        assert _net_stats(d) == (4, 1)
         d.setParam("sort.dict", 0)
         assert np.array_equal(gpu_sort_u32(d, p, few), oracle.sort_u32(few))
-        assert _net_stats(d) == (4, 0)
+        assert _net_stats(d) == (5, 1)
+        assert np.array_equal(gpu_sort_kv(d, p, pairs), oracle.sort_kv32(pairs))
+        assert _net_stats(d) == (6, 1)
         d.setParam("sort.dict", 1)
         assert np.array_equal(gpu_sort_u32(d, p, few), oracle.sort_u32(few))
-        assert _net_stats(d) == (5, 1)
+        assert _net_stats(d) == (7, 2)
         # keys that fit never see the net
         u = oracle.keys_u32(n, seed=8)
         assert np.array_equal(gpu_sort_u32(d, p, u), oracle.sort_u32(u))
-        assert _net_stats(d) == (5, 1)
+        assert _net_stats(d) == (7, 2)
+    finally:
+        p.close(); DeviceUtils.deallocate(d)
+
+
+def test_sample_flags_heavily_repeated_keys_before_the_passes_move_them():
+    """The large sort's first kernel looks at 2048 sampled keys (hybrid_kernels.hpp sample_accumulate): when they repeat
+    themselves so often that some value must outgrow its slab, the overflow flag is up before pass 1 starts, both passes leave at
+    their first instruction and the net starts at once.  Keys that fit never trip it (uniform, sorted, keys computed from their
+    index); keys computed from their index that DO repeat are caught although evenly spaced samples of them never would be.
+    u32 / u64 keys and pairs, bit-exact; the passes' time shows whether they moved keys."""
+    rng = np.random.RandomState(23)
+    n = 1 << 25
+    d = DeviceUtils.allocate()
+    p = Pprims()
+    try:
+        set_algo(d, (-1, 8, -1))
+        d.setParam("sort.msd2", 2)
+        idx = np.arange(n, dtype=np.uint32)
+        uniform = oracle.keys_u32(n, seed=5)
+        (_, prof) = _profiled(d, lambda: gpu_sort_u32(d, p, uniform))
+        real_pass = prof["msd2_pass1_u32"][1]
+        assert real_pass > 0.04, prof   # 128 MiB in, 128 MiB out
+        vals = rng.randint(0, 2**32, 3000, dtype=np.uint64).astype(np.uint32)
+        cases = (("3000 values", vals[rng.randint(0, 3000, n)], True),
+                 ("16 values", vals[rng.randint(0, 16, n)], True),
+                 ("values from the index", (idx * np.uint32(2654435761) >> np.uint32(22)) * np.uint32(0x00400801), True),
+                 ("one value on 10 % of the keys", np.where(rng.rand(n) < 0.10, np.uint32(77), uniform).astype(np.uint32), True),
+                 ("uniform", uniform, False),
+                 ("sorted", np.sort(uniform), False),
+                 ("index times a constant", idx * np.uint32(2654435761), False))
+        for name, keys, repeated in cases:
+            runs = _net_stats(d)[0]
+            got, prof = _profiled(d, lambda: gpu_sort_u32(d, p, keys))
+            assert np.array_equal(got, np.sort(keys)), name
+            if repeated:
+                assert prof["msd2_pass1_u32"][1] < 0.3 * real_pass and prof["msd2_pass2_u32"][1] < 0.3 * real_pass, (name, prof)
+                assert _net_stats(d)[0] == runs + 1, name
+            else:
+                assert prof["msd2_pass1_u32"][1] > 0.6 * real_pass, (name, prof)
+                assert _net_stats(d)[0] == runs, name
+        # the stable form: u64 keys and pairs (the sample looks at the KEY of a pair)
+        few = vals[rng.randint(0, 1000, n)]
+        k64 = (few.astype(np.uint64) << np.uint64(32)) | few.astype(np.uint64)
+        got, prof = _profiled(d, lambda: gpu_sort_u64(d, p, k64))
+        assert np.array_equal(got, np.sort(k64))
+        passes = [ms for k, (c, ms) in prof.items() if "_pass" in k]
+        assert len(passes) == 2 and max(passes) < 0.04, prof
+        pairs = few.astype(np.uint64) | (idx.astype(np.uint64) << np.uint64(32))
+        got, prof = _profiled(d, lambda: gpu_sort_kv(d, p, pairs))
+        assert np.array_equal(got, pairs[np.argsort(few, kind="stable")])
+        assert prof["msd2s_pass1_kv32"][1] < 0.04 and prof["msd2s_pass2_kv32"][1] < 0.04, prof
+        # pairs with distinct keys and one repeated VALUE fit: the value is not looked at
+        pairs = uniform.astype(np.uint64) | (np.uint64(9) << np.uint64(32))
+        runs = _net_stats(d)[0]
+        got = gpu_sort_kv(d, p, pairs)
+        assert np.array_equal(got, np.sort(uniform).astype(np.uint64) | (np.uint64(9) << np.uint64(32)))
+        assert _net_stats(d)[0] == runs
+        d.checkFault()
+    finally:
+        p.close(); DeviceUtils.deallocate(d)
+
+
+def test_pairs_with_few_valued_keys_take_one_stable_pass_on_the_dictionary_rank():
+    """{key, value} pairs whose keys take at most 256 values (group-by keys with a payload): the net builds the dictionary of the
+    KEYS and sorts by ONE stable pass on the key's rank in it (hybrid_kernels.hpp coop_dict_pair_sort, dict_kernels.hpp
+    DictPairIO) instead of four LSD passes.  Stability is what the values show: equal keys keep their input order, bit-exact
+    against the oracle (the reference's CPU sort is stable: RadixSort.cpp:58-104).  Edge cases: one value, the all-ones key among
+    the values, 256 values with a rare one, an odd element count, a key the 16 Ki-sample dictionary cannot know (falls through to
+    the LSD passes with the input untouched), 257 values (no dictionary), sort.rank = 0."""
+    rng = np.random.RandomState(31)
+    d = DeviceUtils.allocate()
+    p = Pprims()
+    try:
+        set_algo(d, (-1, 8, -1))
+
+        def check(keys, counted, name):
+            n = keys.size
+            pairs = keys.astype(np.uint64) | (rng.randint(0, 2**32, n, dtype=np.uint64) << np.uint64(32))
+            runs, cnt = _net_stats(d)
+            got = gpu_sort_kv(d, p, pairs)
+            assert np.array_equal(got, oracle.sort_kv32(pairs)), name
+            assert _net_stats(d) == (runs + 1, cnt + (1 if counted else 0)), (name, _net_stats(d))
+
+        def vals(k):
+            return rng.randint(0, 2**32, k, dtype=np.uint64).astype(np.uint32)
+
+        n = 3000001
+        check(np.full(n, 0xdeadbeef, dtype=np.uint32), True, "one value")
+        check(vals(2)[rng.randint(0, 2, n)], True, "two values")
+        check(vals(40)[rng.randint(0, 40, n)], True, "40 values")
+        check(np.concatenate([vals(100), np.array([0xffffffff, 0], dtype=np.uint32)])[rng.randint(0, 102, n)], True, "0 and the all-ones key among the values")
+        check(np.where(rng.rand(n) < 0.5, np.uint32(0xffffffff), np.uint32(0xfffffffe)).astype(np.uint32), True, "all ones and its neighbour")
+        w = 1.0 / (np.arange(256) + 8)
+        check(vals(256)[rng.choice(256, n, p=w / w.sum())], True, "256 values, skewed")
+        check(np.sort(vals(64)[rng.randint(0, 64, n)]), True, "64 values, keys already in order")
+        check(rng.randint(0, 256, 1 << 23).astype(np.uint32), True, "8 Mi pairs, low byte only")
+        odd = vals(16)[rng.randint(0, 16, n)]
+        odd[2345678] = np.uint32(0x01234567)
+        check(odd, False, "a key the sample cannot see")
+        check(vals(300)[rng.randint(0, 300, n)], False, "300 values")
+        d.setParam("sort.rank", 0)
+        check(vals(40)[rng.randint(0, 40, n)], True, "40 values, ballot ranking")
+        d.setParam("sort.rank", 1)
+        # the 64-Mi row of the benchmark, once: sortedness by key, and every key's values in input order
+        n = 1 << 26
+        keys = vals(256)[rng.randint(0, 256, n)]
+        pairs = keys.astype(np.uint64) | (np.arange(n, dtype=np.uint64) << np.uint64(32))
+        got = gpu_sort_kv(d, p, pairs)
+        gk = (got & np.uint64(0xffffffff)).astype(np.uint32)
+        gv = (got >> np.uint64(32)).astype(np.uint32)
+        assert np.all(gk[1:] >= gk[:-1])
+        assert np.all((gv[1:] > gv[:-1]) | (gk[1:] != gk[:-1]))   # values = input positions: ascending inside every run of equal keys
+        assert np.array_equal(keys[gv], gk)
+        d.checkFault()
     finally:
         p.close(); DeviceUtils.deallocate(d)
 

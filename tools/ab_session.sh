@@ -6,6 +6,6 @@ for rep in 1 2 3; do
   for lib in ${LIBS//,/ }; do
     [ "$lib" = "cur" ] && lib=""
     printf "%-8s " "lib$lib"
-    ADLHIP_LIB=$PWD/oclradixsort_amd/lib/libadlhip$lib.so python tools/sweep.py --steps $STEPS --n $N --kind $KIND --configs $CFG 2>&1 | tail -1
+    ADLHIP_LIB=$PWD/oclradixsort_amd/lib/libadlhip$lib.so python tools/sweep.py --steps $STEPS --n $N --kind $KIND --configs=$CFG 2>&1 | tail -1
   done
 done
