@@ -581,6 +581,48 @@ def main():
             except Exception as e:
                 dists["error"] = repr(e)[:300]
         out["distributions_64Mi_u32"] = dists
+        # ... and {key, value} pairs (config #3's shape) whose keys repeat: group-by keys with a payload.  At most 256 values: one
+        # stable pass on the key's rank in a dictionary, inside the net; more: its four LSD passes.  Values = input positions, so
+        # stability is checked exactly: ascending inside every run of equal keys.
+        pdists = {}
+        if n == N_KEYS and not args.no_other_configs:
+            try:
+                ii = np.arange(n, dtype=np.uint32)
+                hh = ii * np.uint32(2654435761)
+                for name, keys in (("16_values", (hh >> np.uint32(28)) * np.uint32(0x11111111)),
+                                   ("256_values", ((hh >> np.uint32(24)) * np.uint32(0x01010101)) ^ np.uint32(0x5a5a0000)),
+                                   ("4096_values", (hh >> np.uint32(20)) * np.uint32(0x00100801))):
+                    host = keys.astype(np.uint64) | (ii.astype(np.uint64) << np.uint64(32))
+                    d2 = DeviceUtils.allocate()
+                    p2 = Pprims()
+                    p2.reserve(d2, 1, n)
+                    b2 = Buffer(d2, n, np.uint64)
+                    ts = []
+                    for t in range(3):
+                        b2.write(host)
+                        DeviceUtils.waitForCompletion(d2)
+                        sw2 = Stopwatch(d2)
+                        sw2.start()
+                        p2.radixSort(d2, b2, n)
+                        sw2.stop()
+                        ts.append(sw2.getMs())
+                    got = b2.toHost()
+                    gk = (got & np.uint64(0xffffffff)).astype(np.uint32)
+                    gv = (got >> np.uint64(32)).astype(np.uint32)
+                    ok = bool(np.all(gk[1:] >= gk[:-1])) and bool(np.all((gv[1:] > gv[:-1]) | (gk[1:] != gk[:-1]))) and bool(np.array_equal(keys[gv], gk))
+                    pdists[name] = {"first_ms": ts[0], "third_ms": ts[2], "sorted_stable_and_a_permutation": ok,
+                                    "net_runs": d2.getParam("stat.net_runs"), "net_counting": d2.getParam("stat.net_counting")}
+                    b2.release()
+                    p2.close()
+                    DeviceUtils.deallocate(d2)
+                    del got, gk, gv, host
+                    if not ok:
+                        raise SystemExit("bench: wrong result on pairs with %s" % name)
+            except SystemExit:
+                raise
+            except Exception as e:
+                pdists["error"] = repr(e)[:300]
+        out["distributions_64Mi_pairs"] = pdists
         p.close()
         info_name = d.getDeviceName()
         DeviceUtils.deallocate(d)
