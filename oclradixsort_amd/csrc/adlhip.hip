@@ -1563,7 +1563,7 @@ int msd2s_sort(adlhip_device* d, E* data, E* tmp, void* work, size_t n, int sort
     constexpr int NK = sizeof(E) == 4 ? 32 : 16;
     // whole-key sorts: keys of few values are sorted by counting (equal keys are interchangeable), pairs with such keys by ONE
     // stable pass on the key's rank among the values (dict_kernels.hpp)
-    adlhip::DictBlock* net_dict = whole && !soa_keys && d->dict_path ? d->d_dict : nullptr;
+    adlhip::DictBlock* net_dict = whole && (!soa_keys || sizeof(E) == 8) && d->dict_path ? d->d_dict : nullptr;
     using CC = adlhip::TileCfg<E, 8, 512, NK>;   // the safety net's tile (it runs in the offsets kernel when a run did not fit)
     // the net's look-back passes: whole keys; SoA input (packed into the first slab area) and sorts on part of the key run its
     // count-scan-scatter passes

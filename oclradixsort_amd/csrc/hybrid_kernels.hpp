@@ -448,8 +448,8 @@ __device__ __forceinline__ int coop_dict_pair_sort(uint64_t* data, uint64_t* tmp
 template <typename E, int NT, int K, int RANK = 1, int P = 0>
 __device__ __forceinline__ void net_sort(E* data, E* tmp, uint32_t n, uint32_t* __restrict__ table, uint32_t* bar, uint32_t* fault,
                                          unsigned char* smem, int key_bits, DictBlock* dict, uint32_t* stats, const OsNet& os,
-                                         uint32_t sample_repeats /* of the sort's first kernel: keys of <= 256 values show ~126, at least 64 */,
-                                         uint32_t target0 = 0u)
+                                         uint32_t sample_repeats /* of the sort's first kernel: keys of <= 256 values show ~436 */,
+                                         uint32_t target0 = 0u, bool barrier_at_end = false /* the caller reads `data` afterwards */)
 {
     uint32_t target = target0;
     const uint32_t wgs = gridDim.x;
@@ -468,6 +468,7 @@ __device__ __forceinline__ void net_sort(E* data, E* tmp, uint32_t n, uint32_t* 
                 __shared__ uint32_t s_val[256];
                 const int done = coop_dict_pair_sort<NT, K, RANK>(data, tmp, n, table, table + 256 * wgs, bar, target, fault, smem, dict, nv, s_val);
                 if (done == 1 && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(stats + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (done == 1 && barrier_at_end) grid_barrier(bar, target, wgs, fault);   // (the LSD passes end with one of their own)
                 if (done != 0) return;
                 __syncthreads();   // (a key missed the dictionary: the LSD passes sort the untouched input)
             }
@@ -2259,8 +2260,8 @@ __global__ __launch_bounds__(NT) void msd2s_offsets_kernel(const uint32_t* __res
                 if (!grid_barrier(bar, target, gridDim.x, fault)) return;
             }
         }
-        net_sort<E, NT, K, RANK, P>(data, tmp, n, ctable, bar, fault, smem, (int)place->sort_bits, soa_keys ? nullptr : dict, stats, os,
-                                    sample_repeats, target);
+        net_sort<E, NT, K, RANK, P>(data, tmp, n, ctable, bar, fault, smem, (int)place->sort_bits, dict, stats, os, sample_repeats, target,
+                                    soa_keys != nullptr);
         if constexpr (sizeof(E) == 8) {
             if (soa_keys) {   // the sort's last phase ends with a grid barrier: `data` is complete
                 for (size_t i = (size_t)blockIdx.x * NT + (size_t)t; i < n; i += (size_t)gridDim.x * NT) {

@@ -2012,6 +2012,19 @@ def test_pairs_with_few_valued_keys_take_one_stable_pass_on_the_dictionary_rank(
         d.setParam("sort.rank", 0)
         check(vals(40)[rng.randint(0, 40, n)], True, "40 values, ballot ranking")
         d.setParam("sort.rank", 1)
+        # keys and values on separate arrays (SortAndScatterKernel's layout): the net packs them, takes the same pass, unpacks
+        for nv, counted in ((1, True), (30, True), (256, True), (400, False)):
+            keys = vals(nv)[rng.randint(0, nv, n)]
+            values = rng.randint(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+            kb = Buffer(d, n, np.uint32); vb = Buffer(d, n, np.uint32)
+            kb.write(keys); vb.write(values)
+            runs, cnt = _net_stats(d)
+            p.radixSortSoA(d, kb, vb, n)
+            gk, gv = kb.toHost(), vb.toHost()
+            kb.release(); vb.release()
+            wk, wv = oracle.sort_soa(keys, values)
+            assert np.array_equal(gk, wk) and np.array_equal(gv, wv), ("SoA", nv)
+            assert _net_stats(d) == (runs + 1, cnt + (1 if counted else 0)), ("SoA", nv, _net_stats(d))
         # the 64-Mi row of the benchmark, once: sortedness by key, and every key's values in input order
         n = 1 << 26
         keys = vals(256)[rng.randint(0, 256, n)]
