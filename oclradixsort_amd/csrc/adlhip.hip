@@ -2029,8 +2029,10 @@ static int create_common(int device_idx, void* stream, bool own, adlhip_device**
         delete d;
         return fail("cannot allocate the large sort's cursors");
     }
-    if (hipMalloc(&d->d_dict, sizeof(adlhip::DictBlock)) != hipSuccess ||
-        hipMemsetAsync(d->d_dict, 0, sizeof(adlhip::DictBlock), d->stream) != hipSuccess) {
+    // (the larger dictionary of dict_big_kernels.hpp lies behind the small one: the kernels find it at d_dict + 1)
+    static_assert(sizeof(adlhip::DictBlock) % 16 == 0, "the second block starts aligned");
+    if (hipMalloc(&d->d_dict, sizeof(adlhip::DictBlock) + sizeof(adlhip::BigDictBlock)) != hipSuccess ||
+        hipMemsetAsync(d->d_dict, 0, sizeof(adlhip::DictBlock) + sizeof(adlhip::BigDictBlock), d->stream) != hipSuccess) {
         if (d->d_dict) hipFree(d->d_dict);
         hipFree(d->d_msd2);
         hipFree(d->d_mid_hist);
@@ -2634,6 +2636,13 @@ int adlhip_get_param(adlhip_device* d, const char* name, int* value)
         HIPCHK(hipMemcpyAsync(v, net_stats(d), 8, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
         *value = (int)v[name[9] == 'c' ? 1 : 0];
+    }
+    else if (!strncmp(name, "debug.net_stamp", 15) && name[15] >= '0' && name[15] <= '9' && !name[16]) {
+        // diagnostic: when workgroup 0 of the last net reached its k-th phase boundary, in 10-ns ticks (low 31 bits; tools/net_phases.py)
+        uint32_t v = 0u;
+        HIPCHK(hipMemcpyAsync(&v, net_stats(d) + 4 + (name[15] - '0'), 4, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        *value = (int)(v & 0x7fffffffu);
     }
     else if (!strcmp(name, "sort.lds_ordered")) *value = d->lds_ordered;
     else if (!strcmp(name, "profile")) *value = d->profile;

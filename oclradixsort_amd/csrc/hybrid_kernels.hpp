@@ -19,6 +19,7 @@
 #include "radix_kernels.hpp"
 #include "onesweep_kernels.hpp"
 #include "dict_kernels.hpp"
+#include "dict_big_kernels.hpp"
 
 namespace adlhip {
 
@@ -440,6 +441,12 @@ __device__ __forceinline__ int coop_dict_pair_sort(uint64_t* data, uint64_t* tmp
     return 1;
 }
 
+// diagnostic: workgroup 0 notes when it reaches the k-th phase boundary of the net (10-ns ticks; "debug.net_stamp<k>")
+__device__ __forceinline__ void net_stamp(uint32_t* stats, int k)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[4 + k] = (uint32_t)wall_clock64();
+}
+
 // The large sort's safety net, run by the workgroups of its offsets kernel when a run did not fit its slab (the input is then
 // untouched: the passes write only slabs).  dict != nullptr (whole-key sorts of keys): first the counting sort of
 // dict_kernels.hpp -- sample, look up and count, fill -- and only if the keys take more than 256 values, or one of them missed the
@@ -455,6 +462,7 @@ __device__ __forceinline__ void net_sort(E* data, E* tmp, uint32_t n, uint32_t* 
     const uint32_t wgs = gridDim.x;
     // stats[0] = nets run, stats[1] = of those, sorted by counting ("stat.net_runs" / "stat.net_counting": tests, bench)
     if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(stats + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    net_stamp(stats, 0);
     constexpr bool PAIRS = sizeof(E) == 8 && P == 4;   // {key, value} pairs (u64 keys: P == 8)
     if (dict && n >= 16384u && sample_repeats >= kDictMinRepeats) {
         if (blockIdx.x == 0) {
@@ -480,6 +488,32 @@ __device__ __forceinline__ void net_sort(E* data, E* tmp, uint32_t n, uint32_t* 
                 return;
             }
             __syncthreads();   // (the fill's LDS is the LSD sort's)
+        }
+    }
+    if constexpr (sizeof(E) == 4) {   // u32 keys of up to 4096 values: the same three phases with the larger dictionary (dict_big_kernels.hpp)
+        if (dict && n >= (1u << 20) && sample_repeats >= kBigMinRepeats) {
+            BigDictBlock* big = reinterpret_cast<BigDictBlock*>(dict + 1);   // (one allocation: adlhip.hip)
+            net_stamp(stats, 1);
+            uint32_t* samples = reinterpret_cast<uint32_t*>(tmp);   // (64 Ki words of the partner array: n >= 2^20)
+            big_dict_sample<NT>(data, n, samples, big);
+            if (!grid_barrier(bar, target, wgs, fault)) return;
+            if (blockIdx.x == 0) big_dict_build<NT>(samples, big, smem);
+            net_stamp(stats, 2);
+            if (!grid_barrier(bar, target, wgs, fault)) return;
+            net_stamp(stats, 3);
+            const uint32_t bnv = __hip_atomic_load(&big->n_values, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (bnv) {
+                big_dict_count_range<NT>(data, n, big, bnv, smem);
+                net_stamp(stats, 4);
+                if (!grid_barrier(bar, target, wgs, fault)) return;
+                net_stamp(stats, 5);
+                if (!__hip_atomic_load(&big->miss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && big_dict_fill_range<NT>(data, n, big, bnv, smem)) {
+                    net_stamp(stats, 6);
+                    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(stats + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+                __syncthreads();
+            }
         }
     }
     if constexpr (P > 0) {

@@ -1886,8 +1886,10 @@ def test_counting_sort_for_keys_with_few_distinct_values():
     # what is not sorted by counting: 257+ values, pairs, partial sorts, the knob
     d, p = fresh()
     try:
+        # (300 values of u32 keys: the larger dictionary, test_u32_keys_of_up_to_4096_values_are_sorted_by_counting; of u64 keys: LSD passes)
         many = vals32(300)[rng.randint(0, 300, n)]
-        assert np.array_equal(gpu_sort_u32(d, p, many), oracle.sort_u32(many))
+        m64 = (many.astype(np.uint64) << np.uint64(32)) | many.astype(np.uint64)
+        assert np.array_equal(gpu_sort_u64(d, p, m64), oracle.sort_u64(m64))
         assert _net_stats(d) == (1, 0)
         few = vals32(16)[rng.randint(0, 16, n)]
         pairs = few.astype(np.uint64) | (np.arange(n, dtype=np.uint64) << np.uint64(32))
@@ -2035,6 +2037,56 @@ def test_pairs_with_few_valued_keys_take_one_stable_pass_on_the_dictionary_rank(
         assert np.all(gk[1:] >= gk[:-1])
         assert np.all((gv[1:] > gv[:-1]) | (gk[1:] != gk[:-1]))   # values = input positions: ascending inside every run of equal keys
         assert np.array_equal(keys[gv], gk)
+        d.checkFault()
+    finally:
+        p.close(); DeviceUtils.deallocate(d)
+
+
+def test_u32_keys_of_up_to_4096_values_are_sorted_by_counting():
+    """u32 keys that repeat up to 4096 values -- categories, codes, dates -- end in the large sort's net like all keys that repeat,
+    and are sorted there by COUNTING with the larger dictionary (dict_big_kernels.hpp: 64 Ki samples, values ordered by a bitonic sort
+    in LDS, 8192 hash slots, one set of counters per workgroup) instead of four LSD passes.  Bit-exact against the oracle
+    (RadixSort.cpp:58-104).  Edge cases: 257 and 4096 values, the all-ones key and 0 among them, skew, sorted input, a key the
+    sample cannot know and 5000 values (both fall through to the LSD passes), element counts that are not multiples of four."""
+    rng = np.random.RandomState(41)
+    d = DeviceUtils.allocate()
+    p = Pprims()
+    try:
+        set_algo(d, (-1, 8, -1))
+
+        def vals(k):
+            v = np.unique(rng.randint(0, 2**32, 2 * k, dtype=np.uint64).astype(np.uint32))
+            rng.shuffle(v)
+            return v[:k]
+
+        def check(keys, counted, name):
+            runs, cnt = _net_stats(d)
+            got = gpu_sort_u32(d, p, keys)
+            assert np.array_equal(got, oracle.sort_u32(keys)), name
+            assert _net_stats(d) == (runs + 1, cnt + (1 if counted else 0)), (name, _net_stats(d))
+
+        n = 3000003
+        check(vals(257)[rng.randint(0, 257, n)], True, "257 values")
+        check(vals(1000)[rng.randint(0, 1000, n)], True, "1000 values")
+        check(vals(4096)[rng.randint(0, 4096, n + 2)], True, "4096 values")
+        check(np.concatenate([vals(2000), np.array([0xffffffff, 0], dtype=np.uint32)])[rng.randint(0, 2002, n)], True, "0 and the all-ones key among 2002")
+        w = 1.0 / (np.arange(1500) + 300)
+        check(vals(1500)[rng.choice(1500, n, p=w / w.sum())], True, "1500 values, skewed (the rarest: 1 key in 3200)")
+        # values so rare that 64 Ki samples miss some of them: the count stops at the first miss, the LSD passes sort
+        w = 1.0 / (np.arange(3000) + 2) ** 1.3
+        check(vals(3000)[rng.choice(3000, n, p=w / w.sum())], False, "3000 values, Zipf-like")
+        check(np.sort(vals(1500)[rng.randint(0, 1500, n + 1)]), True, "1500 values, in order")
+        check((np.arange(n, dtype=np.uint32) * np.uint32(2654435761) >> np.uint32(20)) * np.uint32(0x00100801), True, "4096 values from the index")
+        odd = vals(800)[rng.randint(0, 800, n)]
+        odd[1234567] = np.uint32(0x01234567)
+        check(odd, False, "a key the sample cannot see")
+        check(vals(5000)[rng.randint(0, 5000, 1 << 23)], False, "5000 values")
+        # one sort at the benchmark's size: multiset and order
+        n = 1 << 26
+        keys = vals(4000)[rng.randint(0, 4000, n)]
+        got = gpu_sort_u32(d, p, keys)
+        assert np.all(got[1:] >= got[:-1]) and np.array_equal(np.bincount(np.searchsorted(np.unique(keys), got), minlength=4000),
+                                                               np.bincount(np.searchsorted(np.unique(keys), keys), minlength=4000))
         d.checkFault()
     finally:
         p.close(); DeviceUtils.deallocate(d)
