@@ -345,7 +345,8 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      samples repeat often enough for that to be possible); if they take at most 256 distinct values
  *                      (whole-key sorts only) it sorts u32 / u64 keys by counting -- dictionary, one read, one write: equal
  *                      keys are interchangeable -- and {key, value} pairs by ONE stable pass on the key's rank in the
- *                      dictionary; it falls through to its LSD passes when a key misses the dictionary
+ *                      dictionary; u32 keys of up to 4096 values are counted with a larger dictionary (64 Ki samples); it
+ *                      falls through to its LSD passes when a key misses the dictionary
  *   "sort.net_lookback" 1 [default] / 0: the LSD passes of the large sort's safety net on whole keys are look-back passes -- the
  *                      one-sweep path's histogram, tables and tile body, taken in turns by the net's resident workgroups, four
  *                      passes at a time (u64 keys: two rounds) -- instead of count -> scan -> scatter passes with per-workgroup
@@ -355,6 +356,8 @@ int adlhip_generate_keys(adlhip_device* dev, int elem_kind, void* dptr, size_t n
  *                      count -> scan -> scatter; the same output bit for bit
  *   "stat.net_runs", "stat.net_counting" (read-only; reading waits for the stream) how often the large sort's safety net has run
  *                      on this handle, and how often it sorted by counting
+ *   "debug.net_stamp0" .. "debug.net_stamp9" (read-only, diagnostic) when workgroup 0 of the handle's last safety net reached its
+ *                      phase boundaries, 10-ns ticks (tools/net_phases.py)
  *   "debug.resident_wgs" workgroups the device certainly keeps resident at once (asked of the runtime at creation); the
  *                      paths whose safety nets hold a grid-wide barrier over 256 workgroups are taken only when it is
  *                      >= 256.  Setting it stands in for a small partition (tests); 0 = ask the device again

@@ -6,10 +6,8 @@
 // whole-key sort is determined by the counts alone (bit for bit what Tahoe/Algorithm/Sort/RadixSort.cpp:58-104 produces): one read
 // and one write do.  The small dictionary's tables (per-wave counters, 1024 slots) stay as they are -- they are the faster ones for
 // few values; this one costs a longer build: 64 Ki sampled keys (every one of 4096 equally likely values is then seen: e^-16 to
-// miss one) and a bitonic sort of the values in LDS.  Keys are looked up by a halving search in the ascending values (twelve LDS
-// reads, sixteen keys of a lane in step so that the latencies overlap -- no probe chains whose longest the 64 lanes of a wave wait
-// for: a hash table at load 1/2 took 0.6 ms to count 64 Mi keys of 4096 values, this 0.15 for any number of values) and counted on
-// one set of 4096 counters per workgroup.
+// miss one), a bitonic sort of the values in LDS, and a hash table of 8192 slots over them.  The count phase keeps the table in LDS
+// with one counter per SLOT: one read and one add per key.
 //
 // Three phases of the net, separated by its grid barriers (net_sort):
 //   1. big_dict_sample         every workgroup fetches its share of the samples; big_dict_build: workgroup 0 makes the dictionary
@@ -26,7 +24,7 @@
 namespace adlhip {
 
 constexpr int kBigMax = 4096;        // values
-constexpr int kBigSlots = 8192;      // slots of the hash SET the build collects the sampled values in (load <= 1/2)
+constexpr int kBigSlots = 8192;      // hash slots over the values (load <= 1/2), in the build's set of sampled values and in the dictionary
 constexpr uint32_t kBigSamples = 65536u;
 constexpr int kBigCopies = 16;
 // the net tries this dictionary if the sort's first kernel counted at least this many repeats among its 16 x 128 samples: 4096
@@ -38,6 +36,8 @@ struct BigDictBlock {                // handle-owned device memory, behind the D
     uint32_t miss;
     uint32_t pad[2];
     uint32_t value[kBigMax];         // ascending, padded with 0xffffffff (which, if it is a value itself, is the last one)
+    uint32_t slot_key[kBigSlots];    // hash table over the values: key (0xffffffff = free; the all-ones key never enters) ...
+    uint32_t slot_idx[kBigSlots];    // ... -> its index in value[]
     // per value, in kBigCopies copies (workgroup w adds to copy w % kBigCopies, the fill phase sums them): 512 workgroups x 4096
     // atomics on ONE copy's 16 KiB queued on a few L2 channels -- 0.3 of the 0.9 ms that 64 Mi keys of 4096 values took
     uint32_t count[kBigCopies * kBigMax];
@@ -164,34 +164,79 @@ __device__ __forceinline__ void big_dict_build(const uint32_t* __restrict__ samp
         }
     }
     for (int i = tid; i < kBigMax; i += NT) blk->value[i] = s_val[i];
+    // the dictionary's hash table, made in LDS (the set of samples is no longer needed) and copied out
+    for (int i = tid; i < kBigSlots; i += NT) s_tab[i] = 0xffffffffu;
+    __syncthreads();
+    for (uint32_t r = (uint32_t)tid; r < distinct; r += (uint32_t)NT) {
+        const uint32_t v = s_val[r];
+        if (v != 0xffffffffu) {
+            uint32_t h = big_dict_hash(v);
+            for (int step = 0; step < kBigSlots; ++step) {
+                if (atomicCAS(&s_tab[h], 0xffffffffu, v) == 0xffffffffu) {
+                    blk->slot_idx[h] = r;   // (global: slots are owned by the thread that won them)
+                    break;
+                }
+                h = (h + 1u) & (uint32_t)(kBigSlots - 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < kBigSlots; i += NT) blk->slot_key[i] = s_tab[i];
     if (tid == 0) blk->n_values = distinct;
 }
 
-// Every workgroup of the grid: look up and count src[0, n).  smem: 32 KiB of the caller's dynamic LDS.
+// Every workgroup of the grid: look up and count src[0, n).  The hash slots carry their own counters: a key costs one LDS read (its
+// first probe; sixteen keys' first probes go out together) and one LDS add -- looking the rank up first (a second, dependent read)
+// or searching the ascending values (thirteen reads, LDS-bound: 0.23-0.54 ms for 64 Mi keys) cost more.  The slot counters are
+// added to the value's global counter at the end.  smem: 64 KiB of the caller's dynamic LDS.
 template <int NT>
 __device__ __forceinline__ void big_dict_count_range(const uint32_t* __restrict__ src, uint32_t n, BigDictBlock* __restrict__ blk,
-                                                     uint32_t nv, unsigned char* smem)
+                                                     uint32_t nv, unsigned char* smem, uint32_t* stamps = nullptr /* diagnostic */)
 {
-    uint32_t* s_val = reinterpret_cast<uint32_t*>(smem);                                   // [kBigMax]
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem + 4 * kBigMax);                     // [kBigMax], one set per workgroup
+    uint32_t* s_key = reinterpret_cast<uint32_t*>(smem);                                   // [kBigSlots]
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem + 4 * kBigSlots);                   // [kBigSlots], one set per workgroup
+    __shared__ uint32_t s_max_cnt;
     const int tid = (int)threadIdx.x;
-    for (int i = tid; i < kBigMax; i += NT) {
-        s_val[i] = blk->value[i];
+    for (int i = tid; i < kBigSlots; i += NT) {
+        s_key[i] = blk->slot_key[i];
         s_cnt[i] = 0u;
     }
+    if (tid == 0) s_max_cnt = 0u;
+    const bool has_max = blk->value[nv - 1u] == 0xffffffffu;   // the all-ones key is a value (the last one); it has no slot
     __syncthreads();
+    if (stamps && blockIdx.x == 0 && tid == 0) stamps[7] = (uint32_t)wall_clock64();
     bool miss = false;
-    // a lane counts runs of equal values by itself and adds a run at its end (constant and ordered keys would otherwise queue 64
-    // lanes on one LDS counter, key after key)
+    uint32_t max_mine = 0u;
+    // a lane counts runs of equal keys by itself and adds a run at its end (constant and ordered keys would otherwise queue 64 lanes
+    // on one LDS counter, key after key)
     uint32_t cur = 0u, run = 0u;
-    auto count = [&](uint32_t ix) {
-        if (ix == cur) {
+    auto count = [&](uint32_t slot) {
+        if (slot == cur) {
             ++run;
         } else {
             if (run) atomicAdd(&s_cnt[cur], run);
-            cur = ix;
+            cur = slot;
             run = 1u;
         }
+    };
+    auto look = [&](uint32_t key, uint32_t first /* s_key[hash(key)] */) {
+        if (key == 0xffffffffu) {
+            if (has_max) ++max_mine;
+            else miss = true;
+            return;
+        }
+        uint32_t h = big_dict_hash(key);
+        uint32_t k = first;
+        for (int step = 0; step < kBigSlots; ++step) {
+            if (k == key) {
+                count(h);
+                return;
+            }
+            if (k == 0xffffffffu) break;
+            h = (h + 1u) & (uint32_t)(kBigSlots - 1);
+            k = s_key[h];
+        }
+        miss = true;
     };
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     const uint32_t nvec = n / 4u;
@@ -200,54 +245,47 @@ __device__ __forceinline__ void big_dict_count_range(const uint32_t* __restrict_
     const uint32_t step = gridDim.x * (uint32_t)NT;
     // (a lane that meets a key outside the dictionary stops counting: skewed categories miss by the thousand, every lane soon has
     // its own, and the LSD passes need not wait for a count that is void.  Looking at a shared flag once per round instead -- 65 K
-    // wave-loads of ONE address that no cache may hold -- cost more than the whole count.)
+    // wave-loads of ONE address that no cache may hold -- did not pay.)
     for (uint32_t i0 = blockIdx.x * (uint32_t)NT + (uint32_t)tid; i0 < nvec; i0 += (uint32_t)U * step) {
-        uint32_t key[4 * U];
+        v4u v[U];
         bool act[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint64_t i = (uint64_t)i0 + (uint64_t)u * step;
             act[u] = i < nvec;
-            v4u v = {0u, 0u, 0u, 0u};
-            if (act[u]) v = vsrc[i];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) key[4 * u + k] = v[k];
+            if (act[u]) v[u] = vsrc[i];
         }
-        uint32_t lo[4 * U];
 #pragma unroll
-        for (int j = 0; j < 4 * U; ++j) lo[j] = 0u;
-#pragma unroll
-        for (uint32_t st = (uint32_t)kBigMax / 2u; st >= 1u; st >>= 1) {   // sixteen searches in step: their LDS reads overlap
-#pragma unroll
-            for (int j = 0; j < 4 * U; ++j) lo[j] += s_val[lo[j] + st - 1u] < key[j] ? st : 0u;
-        }
-        uint32_t found[4 * U];
-#pragma unroll
-        for (int j = 0; j < 4 * U; ++j) found[j] = s_val[lo[j]];
-#pragma unroll
-        for (int j = 0; j < 4 * U; ++j) {
-            if (act[j >> 2]) {
-                if (lo[j] < nv && found[j] == key[j]) count(lo[j]);
-                else miss = true;
+        for (int u = 0; u < U; ++u) {
+            if (act[u]) {
+                const uint32_t f0 = s_key[big_dict_hash(v[u][0])], f1 = s_key[big_dict_hash(v[u][1])];
+                const uint32_t f2 = s_key[big_dict_hash(v[u][2])], f3 = s_key[big_dict_hash(v[u][3])];
+                look(v[u][0], f0);
+                look(v[u][1], f1);
+                look(v[u][2], f2);
+                look(v[u][3], f3);
             }
         }
         if (miss) break;
     }
     if (blockIdx.x == 0 && (uint32_t)tid < n - nvec * 4u) {   // the last n % 4 keys
         const uint32_t key = src[nvec * 4u + (uint32_t)tid];
-        const uint32_t r = big_dict_rank(key, s_val);
-        if (r < nv && s_val[r] == key) count(r);
-        else miss = true;
+        look(key, s_key[big_dict_hash(key)]);
     }
     if (run) atomicAdd(&s_cnt[cur], run);
+    if (max_mine) atomicAdd(&s_max_cnt, max_mine);
+    if (stamps && blockIdx.x == 0 && tid == 0) stamps[8] = (uint32_t)wall_clock64();
     const int any_miss = __syncthreads_or(miss);
+    if (stamps && blockIdx.x == 0 && tid == 0) stamps[9] = (uint32_t)wall_clock64();
     if (any_miss) {
         if (tid == 0) __hip_atomic_store(&blk->miss, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-        for (uint32_t i = (uint32_t)tid; i < nv; i += (uint32_t)NT) {
+        uint32_t* mine = blk->count + (blockIdx.x % (uint32_t)kBigCopies) * (uint32_t)kBigMax;
+        for (int i = tid; i < kBigSlots; i += NT) {
             const uint32_t c = s_cnt[i];
-            if (c) __hip_atomic_fetch_add(&blk->count[(blockIdx.x % (uint32_t)kBigCopies) * (uint32_t)kBigMax + i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c) __hip_atomic_fetch_add(&mine[blk->slot_idx[i]], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (tid == 0 && s_max_cnt) __hip_atomic_fetch_add(&mine[nv - 1u], s_max_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

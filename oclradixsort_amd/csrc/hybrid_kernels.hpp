@@ -503,7 +503,7 @@ __device__ __forceinline__ void net_sort(E* data, E* tmp, uint32_t n, uint32_t* 
             net_stamp(stats, 3);
             const uint32_t bnv = __hip_atomic_load(&big->n_values, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (bnv) {
-                big_dict_count_range<NT>(data, n, big, bnv, smem);
+                big_dict_count_range<NT>(data, n, big, bnv, smem, stats + 4);
                 net_stamp(stats, 4);
                 if (!grid_barrier(bar, target, wgs, fault)) return;
                 net_stamp(stats, 5);

@@ -18,6 +18,10 @@ for D in (300, 1000, 4096):
         sw = Stopwatch(d); sw.start(); p.radixSort(d, b, n); sw.stop()
     st = [d.getParam("debug.net_stamp%d" % k) for k in range(7)]
     us = [((st[k + 1] - st[k]) & 0x7fffffff) / 100.0 for k in range(6)]
+    ex = [d.getParam("debug.net_stamp%d" % k) for k in (7, 8, 9)]
+    print("   inside the count (workgroup 0): tables into LDS %.0f us | keys %.0f | waiting for the other waves %.0f | counters out %.0f" %
+          (((ex[0] - st[3]) & 0x7fffffff) / 100.0, ((ex[1] - ex[0]) & 0x7fffffff) / 100.0, ((ex[2] - ex[1]) & 0x7fffffff) / 100.0,
+           ((st[4] - ex[2]) & 0x7fffffff) / 100.0))
     print("D=%d n=%d sort %.3f ms; us: small-dictionary attempt %.0f | build %.0f | barrier %.0f | count %.0f | barrier %.0f | fill %.0f" % ((D, n, sw.getMs()) + tuple(us)), flush=True)
     b.release()
 p.close(); DeviceUtils.deallocate(d)
