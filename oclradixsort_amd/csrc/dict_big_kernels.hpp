@@ -69,17 +69,6 @@ __device__ __forceinline__ size_t big_sample_index(uint32_t k, uint32_t n)
     return (size_t)(lo + (((unsigned long long)h * (hi - lo)) >> 32));
 }
 
-// Number of dictionary values below `key` (s_val: the 4096 words, ascending, padded with 0xffffffff): at most 4095.  The key is in
-// the dictionary iff the result r is < n_values and s_val[r] == key -- the all-ones key included: it finds itself if it is a value
-// (the last one), and the first pad, at n_values, if it is not.
-__device__ __forceinline__ uint32_t big_dict_rank(uint32_t key, const uint32_t* __restrict__ s_val)
-{
-    uint32_t lo = 0u;
-#pragma unroll
-    for (uint32_t step = (uint32_t)kBigMax / 2u; step >= 1u; step >>= 1) lo += s_val[lo + step - 1u] < key ? step : 0u;
-    return lo;
-}
-
 // Every workgroup: its share of the 64 Ki samples into `samples` (scratch: the sort's partner array, idle until the LSD passes) and of
 // the counters' clearing -- one workgroup alone took 80 us to fetch 64 Ki scattered keys.  A grid barrier follows.
 template <int NT>
